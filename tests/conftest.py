@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    path = os.path.join(GOLDEN, f"{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"golden fixture {name}.npz not present")
+    z = np.load(path, allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def golden_names(pred=lambda n: True):
+    if not os.path.isdir(GOLDEN):
+        return []
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and pred(f[:-4]))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = load_golden(name)
+        return cache[name]
+
+    return get
