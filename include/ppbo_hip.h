@@ -1,0 +1,182 @@
+/*
+ * ppbo_hip.h -- C-ABI of libppbo_hip.so: the MI355X (gfx950) GP-surrogate and
+ * acquisition engine behind PPBO's GPModel / next_query() / Hsampler surface.
+ *
+ * The reference (AaltoPML/PPBO) has no FFI layer: its boundary is a Python
+ * object surface.  Each entry point below names the reference expression it
+ * replaces (file:line relative to the reference repository).  INTEGRATION.md
+ * shows the ctypes stub a PPBO maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - every function returns int: 0 ok, <0 invalid argument, >0 HIP error code
+ *     (PPBO_ERR_NOT_PD = 1001 is the only non-HIP positive code).  Nothing throws.
+ *   - pointers named d_* are DEVICE pointers owned by the caller (row-major,
+ *     C-contiguous float64 unless stated); h_* are HOST pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     Functions with host outputs synchronise that stream before returning.
+ *   - one ppbo_ctx per process/device; a ctx owns only private workspaces.
+ */
+#ifndef PPBO_HIP_H
+#define PPBO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPBO_ABI_VERSION 1
+#define PPBO_ERR_NOT_PD 1001
+
+typedef struct ppbo_ctx ppbo_ctx;
+
+/* kernel ids: src/kernels.py:19 (SE), :27 (RQ, alpha=2), :36 (camphor-copper, D must be 6) */
+enum { PPBO_KERNEL_SE = 0, PPBO_KERNEL_RQ = 1, PPBO_KERNEL_CAMPHOR = 2 };
+
+/* candidate score folded into the running argmax */
+enum {
+  PPBO_SCORE_MEAN = 0,         /* mu(x): what mu_star maximises, src/gp_model.py:422 */
+  PPBO_SCORE_POINTWISE_EI = 1, /* (mu-mu*)Phi(z)+s phi(z): G=1 closed form of src/acquisition.py:72-81 */
+  PPBO_SCORE_VARIANCE = 2      /* sigma^2(x): G=1 form of varmax, src/acquisition.py:170-178 */
+};
+
+int ppbo_abi_version(void);
+int ppbo_ctx_create(int device, ppbo_ctx** out);
+int ppbo_ctx_destroy(ppbo_ctx* ctx);
+/* copies the last error text of this ctx into buf (NUL terminated) */
+int ppbo_last_error(ppbo_ctx* ctx, char* buf, size_t n);
+
+/* ---- K1: Gram matrix with the closed-form shrinkage --------------------
+ * replaces GPModel.create_Gramian (src/gp_model.py:147-151) =
+ * kernel(X,X,theta) (src/kernels.py:19-53) + regularize_covariance
+ * (src/misc.py:71-88; SVD round trip == identity, shrink == (1-s)K + s tr(K)/N I).
+ * d_X[N,D] -> d_Sigma[N,N]. */
+int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D,
+              const double h_theta[3], double shrink, double* d_Sigma, void* stream);
+
+/* ---- K2: raw cross-covariance ------------------------------------------
+ * replaces GPModel.create_Gramian_nonsquare (src/gp_model.py:153-155).
+ * d_X1[n1,D], d_X2[n2,D] -> d_K[n1,n2] (row stride ldk >= n2). */
+int ppbo_cross_cov(ppbo_ctx* ctx, int kernel_id, const double* d_X1, int n1,
+                   const double* d_X2, int n2, int D, const double h_theta[3],
+                   double* d_K, int ldk, void* stream);
+
+/* ---- K6: dense SPD factor / inverse (fp64, hand-written blocked kernels) --
+ * ppbo_potrf: in-place lower Cholesky of d_A[N,N] (upper triangle untouched).
+ *   *h_info = 0 on success, k>0 if the leading minor of order k is not PD
+ *   (LAPACK convention); return value PPBO_ERR_NOT_PD in that case.
+ * ppbo_pd_inverse replaces misc.pd_inverse (src/misc.py:96-100): d_Ainv = A^-1
+ *   (full symmetric matrix written). */
+int ppbo_potrf(ppbo_ctx* ctx, double* d_A, int N, int lda, int* h_info, void* stream);
+int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int* h_info, void* stream);
+
+/* ---- K5: Laplace terms of the projective-preference likelihood -----------
+ * replaces sum_Phi/sum_Phi_vec (src/gp_model.py:176-218), the likelihood part of
+ * T (:221-226), beta of T_grad (:234-238) and create_Lambda (:249-274).
+ * Design contract (src/feedback_processing.py:110-130): N = n_q (m+1); row
+ * q(m+1) is the observation of query q, the next m rows its pseudo-observations.
+ * Outputs (any may be NULL): d_Tlik[1] = -(1/m) sum_q sum_j Phi(Delta_qj/sqrt2);
+ * d_beta[N]; d_lam_diag[N], d_lam_off[N] = Lambda in star-graph form
+ * (off[j] = Lambda[obs(j), j] for pseudo rows, 0 on observation rows). */
+int ppbo_laplace_terms(ppbo_ctx* ctx, const double* d_f, int N, int m, double sigma,
+                       double* d_Tlik, double* d_beta, double* d_lam_diag,
+                       double* d_lam_off, void* stream);
+
+/* ---- a-8: f_MAP by trust-region Newton -----------------------------------
+ * replaces GPModel.update_fMAP's scipy.optimize.minimize(method='trust-exact')
+ * (src/gp_model.py:354-389) for ONE start vector d_f_init[N].
+ * Radius rules follow SciPy's trust-region driver (initial 1, max 1000,
+ * eta 0.15); the subproblem is a More-Sorensen iteration on device Cholesky
+ * factors.  Stops when |grad T|_2 < gtol or after maxiter outer iterations. */
+typedef struct ppbo_fit_opts {
+  double gtol;    /* reference default 1e-4 (SciPy); 100 during initialisation (src/gp_model.py:365-366) */
+  int maxiter;    /* <=0: 200*N like SciPy */
+  int verbose;
+} ppbo_fit_opts;
+typedef struct ppbo_fit_stats {
+  int iterations;   /* outer trust-region iterations */
+  int n_cholesky;   /* factorizations attempted */
+  int converged;    /* 1 if |grad| < gtol */
+  double T;         /* T(f_MAP) (src/gp_model.py:221-226) */
+  double gradnorm;  /* |grad T(f_MAP)|_2 */
+} ppbo_fit_stats;
+int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double sigma,
+                  const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
+                  ppbo_fit_stats* h_stats, void* stream);
+
+/* T(f) and grad T(f) for a given f (src/gp_model.py:221-240); h_T / d_grad may be NULL */
+int ppbo_T_and_grad(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_f, int N, int m,
+                    double sigma, double* h_T, double* d_grad, void* stream);
+
+/* ---- posterior state for prediction ---------------------------------------
+ * replaces update_model's tail (src/gp_model.py:111-117) and the per-call
+ * A = Sigma^-1 - Sigma^-1 P Sigma^-1 of mu_Sigma_pred (:449).  With
+ * W = -Lambda_MAP, B = Sigma^-1 + W = L_B L_B^T, R = L_B^-1:
+ *   d_alpha[N] = Sigma^-1 f_MAP;  d_G[N,N] = R W (block lower triangular);
+ *   k*^T A k* = k*^T W k* - |G k*|^2   (Woodbury; identical operator).
+ * d_P (optional, may be NULL) = posterior_covariance = B^-1 (src/gp_model.py:117).
+ * Returns PPBO_ERR_NOT_PD when B is not positive definite (the reference prints
+ * '---!!!--- Posterior covariance matrix is not PSD ---!!!---' and continues). */
+int ppbo_posterior(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fMAP, int N, int m,
+                   double sigma, double* d_alpha, double* d_lam_diag, double* d_lam_off,
+                   double* d_G, double* d_P, int* h_info, void* stream);
+
+/* ---- K2+K3+K4: batched candidate scoring with on-device argmax ------------
+ * replaces mu_pred (src/gp_model.py:454-458) / diag of mu_Sigma_pred (:441-452)
+ * called once per candidate by mu_star's differential evolution (:415-437) and
+ * by EI/varmax (src/acquisition.py:72-81,170-178).
+ * d_Xc[M,D] candidates in [0,1]^D.  Outputs (NULL to skip): d_mu[M], d_var[M],
+ * d_score[M]; h_best_val / h_best_idx = max score and its FIRST index
+ * (np.argmax semantics).  d_G may be NULL when only the mean is wanted. */
+typedef struct ppbo_model {
+  int kernel_id, N, D, m;
+  double theta[3];
+  const double* d_X;        /* [N,D] */
+  const double* d_alpha;    /* [N]   */
+  const double* d_lam_diag; /* [N]  Lambda_MAP diagonal   */
+  const double* d_lam_off;  /* [N]  Lambda_MAP star edges */
+  const double* d_G;        /* [N,N] R W, see ppbo_posterior */
+} ppbo_model;
+int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
+                 int score_kind, double mustar, double* d_mu, double* d_var, double* d_score,
+                 double* h_best_val, int64_t* h_best_idx, void* stream);
+
+/* full predictive covariance of small sets (the G=70 line grid of EI):
+ * d_cov[M,M] = (1-s)K(Xc,Xc) + s sigma_f^2 I - K*^T A K*  (src/gp_model.py:447-450) */
+int ppbo_predict_cov(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int M,
+                     double shrink, double* d_mu, double* d_cov, void* stream);
+
+/* ---- K10: Monte-Carlo line acquisition -------------------------------------
+ * replaces EI / varmax (src/acquisition.py:72-81, 170-178) for B lines of G points
+ * with stored standard-normal draws d_z[S,G]: f = mu + chol(cov) z.
+ * d_grid[B,G,D] -> d_ei[B], d_varmax[B] (either may be NULL). */
+int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, int B, int G,
+                  double shrink, const double* d_z, int S, double mustar, double jitter,
+                  double* d_ei, double* d_varmax, void* stream);
+
+/* ---- K7/K8/K9: random Fourier features --------------------------------------
+ * ppbo_rff_project replaces Hsampler.phiVec/update_phi_X
+ *   (src/random_fourier_sampler.py:45-47,57-58): d_Phi[F,N] = sqrt(2 sf^2/F) cos(W X^T + b).
+ * ppbo_rff_score replaces phi(x)^T omega (:166,170) batched over M candidates with
+ *   an on-device argmax (Phi(Xc) never materialised).
+ * ppbo_rff_terms replaces S, S_grad, diag(S_hessian) (:106-122); outputs may be NULL. */
+int ppbo_rff_project(ppbo_ctx* ctx, const double* d_X, int N, int D, const double* d_W, int F,
+                     const double* d_b, double sigma_f, double* d_Phi, void* stream);
+int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const double* d_W, int F,
+                   const double* d_b, double sigma_f, const double* d_omega, double* d_score,
+                   double* h_best_val, int64_t* h_best_idx, void* stream);
+int ppbo_rff_terms(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, double sigma,
+                   const double* d_omega, double* h_S, double* d_grad, double* d_hdiag, void* stream);
+
+/* ---- generic fp64 MFMA GEMM (exposed for tests and host-side composition) ----
+ * C[M,N] = alpha op(A) op(B) + beta C.  transA/transB: 0 = as stored, 1 = transposed. */
+int ppbo_dgemm(ppbo_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha,
+               const double* d_A, int lda, const double* d_B, int ldb, double beta,
+               double* d_C, int ldc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPBO_HIP_H */

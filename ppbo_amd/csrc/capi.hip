@@ -1,0 +1,85 @@
+// Context management and error plumbing of libppbo_hip.so.
+#include "common.h"
+
+int ppbo_set_error(ppbo_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    ctx->err = buf;
+  }
+  return code;
+}
+
+void* ppbo_workspace(ppbo_ctx* ctx, int slot, size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  if (ctx->ws_bytes[slot] >= bytes) return ctx->ws[slot];
+  if (ctx->ws[slot]) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(ctx->ws[slot]);
+    ctx->ws[slot] = nullptr;
+    ctx->ws_bytes[slot] = 0;
+  }
+  size_t want = bytes + bytes / 8;  // headroom so small growth does not realloc
+  void* p = nullptr;
+  if (hipMalloc(&p, want) != hipSuccess) {
+    ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "workspace slot %d: hipMalloc(%zu) failed", slot, want);
+    return nullptr;
+  }
+  ctx->ws[slot] = p;
+  ctx->ws_bytes[slot] = want;
+  return p;
+}
+
+void* ppbo_pinned(ppbo_ctx* ctx, size_t bytes) {
+  if (ctx->pinned_bytes >= bytes) return ctx->pinned;
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  ctx->pinned = nullptr;
+  ctx->pinned_bytes = 0;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  ctx->pinned = p;
+  ctx->pinned_bytes = bytes;
+  return p;
+}
+
+extern "C" {
+
+int ppbo_abi_version(void) { return PPBO_ABI_VERSION; }
+
+int ppbo_ctx_create(int device, ppbo_ctx** out) {
+  if (!out) return -1;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return (int)e;
+  if (device < 0 || device >= n) return -1;
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return (int)e;
+  ppbo_ctx* c = new (std::nothrow) ppbo_ctx();
+  if (!c) return -2;
+  c->device = device;
+  *out = c;
+  return 0;
+}
+
+int ppbo_ctx_destroy(ppbo_ctx* ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < ppbo_ctx::WS_COUNT; ++i)
+    if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  delete ctx;
+  return 0;
+}
+
+int ppbo_last_error(ppbo_ctx* ctx, char* buf, size_t n) {
+  if (!ctx || !buf || n == 0) return -1;
+  snprintf(buf, n, "%s", ctx->err.c_str());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// Shared host/device helpers for libppbo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/ppbo_hip.h"
+
+// A ctx owns private device workspaces (grown on demand, freed on destroy) and
+// the last error string.  No global mutable state.
+struct ppbo_ctx {
+  int device = 0;
+  std::string err;
+  // named workspace slots
+  enum { WS_KSTAR = 0, WS_PART, WS_SCRATCH, WS_LINALG, WS_LINALG2, WS_VEC, WS_SMALL, WS_COUNT };
+  void* ws[WS_COUNT] = {};
+  size_t ws_bytes[WS_COUNT] = {};
+  void* pinned = nullptr;  // small pinned host staging buffer
+  size_t pinned_bytes = 0;
+};
+
+int ppbo_set_error(ppbo_ctx* ctx, int code, const char* fmt, ...);
+// returns a device pointer of at least `bytes` (contents undefined); nullptr on failure
+void* ppbo_workspace(ppbo_ctx* ctx, int slot, size_t bytes);
+void* ppbo_pinned(ppbo_ctx* ctx, size_t bytes);
+
+#define PPBO_HIP_CHECK(ctx, expr)                                                      \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess)                                                              \
+      return ppbo_set_error((ctx), (int)_e, "%s failed: %s (%s:%d)", #expr,            \
+                            hipGetErrorString(_e), __FILE__, __LINE__);                \
+  } while (0)
+
+#define PPBO_LAUNCH_CHECK(ctx) PPBO_HIP_CHECK(ctx, hipGetLastError())
+
+#define PPBO_REQUIRE(ctx, cond, msg)                                    \
+  do {                                                                  \
+    if (!(cond)) return ppbo_set_error((ctx), -1, "invalid argument: %s", msg); \
+  } while (0)
+
+// ---- kernel-function parameters (host-prepared, passed by value) ------------
+struct KernParams {
+  double sf2;      // sigma_f^2
+  double c0;       // SE: 0.5/l^2     RQ: 1/(4 l^2)    camphor: 2/l^2
+  double c1;       // camphor: 0.5/(l+0.05)^2
+};
+
+static inline KernParams make_kern_params(int kernel_id, const double theta[3]) {
+  KernParams p;
+  const double l = theta[1], sf = theta[2];
+  p.sf2 = sf * sf;
+  p.c1 = 0.0;
+  if (kernel_id == PPBO_KERNEL_SE) p.c0 = 0.5 / (l * l);
+  else if (kernel_id == PPBO_KERNEL_RQ) p.c0 = 1.0 / (4.0 * l * l);
+  else { p.c0 = 2.0 / (l * l); p.c1 = 0.5 / ((l + 0.05) * (l + 0.05)); }
+  return p;
+}
+
+#ifdef __HIPCC__
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// 64-lane wavefront reductions (gfx950: wave = 64)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Kernel value from accumulated per-dimension terms.
+//   SE / RQ : s = sum_d (x_d - y_d)^2
+//   camphor : s = c0 * sum_{d in 0,1,3,4,5} sin^2(pi |dx_d|) + c1 * dx_2^2  (already scaled)
+template <int KID>
+__device__ __forceinline__ double kern_finish(double s, const KernParams& p) {
+  if (KID == PPBO_KERNEL_SE) return p.sf2 * exp(-p.c0 * s);
+  if (KID == PPBO_KERNEL_RQ) {
+    const double t = 1.0 + s * p.c0;
+    return p.sf2 / (t * t);
+  }
+  return p.sf2 * exp(-s);
+}
+
+template <int KID>
+__device__ __forceinline__ double kern_term(double dx, int d, const KernParams& p) {
+  if (KID == PPBO_KERNEL_CAMPHOR) {
+    if (d == 2) return p.c1 * dx * dx;
+    const double sn = sinpi(fabs(dx));
+    return p.c0 * sn * sn;
+  }
+  return dx * dx;
+}
+#endif

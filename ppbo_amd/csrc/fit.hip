@@ -1,0 +1,477 @@
+// K5 + a-8: Laplace terms of the projective-preference likelihood, f_MAP by
+// trust-region Newton, and the posterior state used by prediction.
+//   reference: gp_model.py:176-274 (sum_Phi, T, T_grad, create_Lambda),
+//              :354-389 (update_fMAP -> scipy trust-exact), :111-117 (posterior covariance).
+//
+// Likelihood terms: Phi(Delta/sqrt2) = erfc(-Delta/2)/2 is the closed form of the
+// reference's Gauss-Hermite-200 quadrature (gp_model.py:192; agrees to 3e-16).
+// One wavefront per query (star): lanes = pseudo-observations, wave-shuffle sums.
+//
+// Trust region: radius rules of SciPy's driver (initial 1, max 1000, eta 0.15,
+// x1/4 when rho<1/4, x2 when rho>3/4 on the boundary); subproblem by the
+// More-Sorensen iteration on lam (Conn/Gould/Toint Alg. 7.3.4 without hard-case
+// refinement): each trial lam = one device Cholesky (potrf) + triangular inverse
+// (trtri) + three GEMVs.  The host loop only reads a handful of scalars per trial.
+#include "linalg.h"
+
+namespace {
+
+constexpr double INV_SQRT_4PI = 0.28209479177387814347;
+
+__global__ __launch_bounds__(256) void laplace_kernel(const double* __restrict__ f, int N, int mblk, int n_q,
+                                                      double sigma, double* __restrict__ tq,
+                                                      double* __restrict__ beta, double* __restrict__ lam_diag,
+                                                      double* __restrict__ lam_off) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n_q) return;
+  const int m = mblk - 1;
+  const int i = q * mblk;
+  const double f0 = f[i];
+  const double c = 1.0 / ((double)m * (sigma * sigma));
+  const double bsc = sigma * (double)m;
+  double sphi = 0.0, sp2 = 0.0, sw = 0.0;
+  for (int r = 1 + lane; r <= m && i + r < N; r += 64) {
+    const int j = i + r;
+    const double delta = (f[j] - f0) / sigma;
+    sphi += 0.5 * erfc(-0.5 * delta);
+    const double p2 = INV_SQRT_4PI * exp(-0.25 * (delta * delta));
+    const double w = 0.5 * c * delta * p2;
+    sp2 += p2;
+    sw += w;
+    if (beta) beta[j] = -p2 / bsc;
+    if (lam_diag) lam_diag[j] = w;
+    if (lam_off) lam_off[j] = -w;
+  }
+  sphi = wave_sum(sphi);
+  sp2 = wave_sum(sp2);
+  sw = wave_sum(sw);
+  if (lane == 0) {
+    if (tq) tq[q] = sphi;
+    if (beta) beta[i] = sp2 / bsc;
+    if (lam_diag) lam_diag[i] = sw;
+    if (lam_off) lam_off[i] = 0.0;
+  }
+}
+
+// out[0] = -(1/m) sum_q tq[q]
+__global__ __launch_bounds__(1024) void tlik_reduce_kernel(const double* __restrict__ tq, int n_q, int m,
+                                                           double* __restrict__ out) {
+  __shared__ double sh[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n_q; i += 1024) s += tq[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    *out = -t / (double)m;
+  }
+}
+
+// g = v - beta (gradient of phi = -T);  out[0] = f.v, out[1] = |g|^2 ; optional grad_T = -g
+__global__ __launch_bounds__(1024) void grad_kernel(const double* __restrict__ f, const double* __restrict__ v,
+                                                    const double* __restrict__ beta, int N,
+                                                    double* __restrict__ g, double* __restrict__ gradT,
+                                                    double* __restrict__ out) {
+  __shared__ double sh[2][16];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    const double gi = v[i] - beta[i];
+    if (g) g[i] = gi;
+    if (gradT) gradT[i] = -gi;
+    a += f[i] * v[i];
+    b += gi * gi;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0.0, sb = 0.0;
+    for (int w = 0; w < 16; ++w) { sa += sh[0][w]; sb += sh[1][w]; }
+    out[0] = sa;
+    out[1] = sb;
+  }
+}
+
+// H = Sinv - Lambda + lam I; optional per-row Gershgorin statistics of the UNSHIFTED H
+__global__ __launch_bounds__(256) void form_shifted_kernel(const double* __restrict__ Sinv, int N, int mblk,
+                                                           const double* __restrict__ lam_diag,
+                                                           const double* __restrict__ lam_off, double lam,
+                                                           double* __restrict__ H, double* __restrict__ rowstats) {
+  __shared__ double sh[2][4];
+  __shared__ double shd[4];
+  const int i = blockIdx.x;
+  const int q0 = (i / mblk) * mblk;      // observation row of i's star
+  const bool is_obs = (i == q0);
+  const double* src = Sinv + (size_t)i * N;
+  double* dst = H + (size_t)i * N;
+  double rs = 0.0, sq = 0.0, dg = 0.0;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    double h = src[j];
+    if (j == i) h -= lam_diag[i];
+    else if (is_obs && j > q0 && j < q0 + mblk) h -= lam_off[j];
+    else if (!is_obs && j == q0) h -= lam_off[i];
+    sq += h * h;
+    if (j == i) { dg = h; h += lam; }
+    else rs += fabs(h);
+    dst[j] = h;
+  }
+  if (rowstats) {
+    rs = wave_sum(rs);
+    sq = wave_sum(sq);
+    dg = wave_sum(dg);  // exactly one lane holds the diagonal, the rest 0
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = rs; sh[1][w] = sq; shd[w] = dg; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      rowstats[i] = shd[0] + shd[1] + shd[2] + shd[3];
+      rowstats[N + i] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+      rowstats[2 * N + i] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    }
+  }
+}
+
+// out: [0] min diag, [1] max(diag+rs), [2] min(diag-rs), [3] fro^2, [4] max(|diag|+rs)
+__global__ __launch_bounds__(1024) void stats_reduce_kernel(const double* __restrict__ rowstats, int N,
+                                                            double* __restrict__ out) {
+  __shared__ double sh[5][16];
+  double mn = INFINITY, gmax = -INFINITY, gmin = INFINITY, fro = 0.0, inf = 0.0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    const double d = rowstats[i], rs = rowstats[N + i];
+    mn = fmin(mn, d);
+    gmax = fmax(gmax, d + rs);
+    gmin = fmin(gmin, d - rs);
+    fro += rowstats[2 * N + i];
+    inf = fmax(inf, fabs(d) + rs);
+  }
+  mn = -wave_max(-mn);
+  gmax = wave_max(gmax);
+  gmin = -wave_max(-gmin);
+  fro = wave_sum(fro);
+  inf = wave_max(inf);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[0][w] = mn; sh[1][w] = gmax; sh[2][w] = gmin; sh[3][w] = fro; sh[4][w] = inf; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k) {
+      sh[0][0] = fmin(sh[0][0], sh[0][k]);
+      sh[1][0] = fmax(sh[1][0], sh[1][k]);
+      sh[2][0] = fmin(sh[2][0], sh[2][k]);
+      sh[3][0] += sh[3][k];
+      sh[4][0] = fmax(sh[4][0], sh[4][k]);
+    }
+    for (int k = 0; k < 5; ++k) out[k] = sh[k][0];
+  }
+}
+
+// p = -u ; fn = f + p ; out: [0]=|p|^2 [1]=g.p   (u = H_lam^-1 g)
+__global__ __launch_bounds__(1024) void step_kernel(const double* __restrict__ u, const double* __restrict__ g,
+                                                    const double* __restrict__ f, int N, double* __restrict__ p,
+                                                    double* __restrict__ fn, double* __restrict__ out) {
+  __shared__ double sh[2][16];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    const double pi = -u[i];
+    p[i] = pi;
+    fn[i] = f[i] + pi;
+    a += pi * pi;
+    b += g[i] * pi;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0.0, sb = 0.0;
+    for (int w = 0; w < 16; ++w) { sa += sh[0][w]; sb += sh[1][w]; }
+    out[0] = sa;
+    out[1] = sb;
+  }
+}
+
+// G[i][j] = (R Lambda)[i][j] for the star-structured Lambda; thread = (row i, star q)
+__global__ __launch_bounds__(256) void g_build_kernel(const double* __restrict__ R, int N, int mblk,
+                                                      const double* __restrict__ lam_diag,
+                                                      const double* __restrict__ lam_off, double* __restrict__ G) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q0 = blockIdx.y * mblk;
+  if (i >= N) return;
+  const double* r = R + (size_t)i * N + q0;
+  double* g = G + (size_t)i * N + q0;
+  const double r0 = r[0];
+  double acc = r0 * lam_diag[q0];
+  for (int k = 1; k < mblk && q0 + k < N; ++k) {
+    const double rk = r[k];
+    const double lo = lam_off[q0 + k];
+    g[k] = rk * lam_diag[q0 + k] + r0 * lo;
+    acc += rk * lo;
+  }
+  g[0] = acc;
+}
+
+struct Vecs {  // one evaluation point
+  double *f, *v, *beta, *ld, *lo, *g;
+  double fSf, gn2, Tlik;
+};
+
+struct FitWork {
+  ppbo_ctx* ctx;
+  hipStream_t s;
+  const double* Sinv;
+  int N, m, mblk, n_q;
+  double sigma;
+  double *H, *Linv;       // N x N each
+  double *tq, *rowstats, *sc, *u, *w, *p, *q;
+  double* hsc;            // pinned host scalars
+  int* d_info;
+};
+
+int eval_point(FitWork& W, Vecs& P) {
+  // v = Sinv f ; laplace terms ; g ; scalars -> host
+  if (int rc = ppbo_gemv_async(W.ctx, W.Sinv, W.N, W.N, P.f, P.v, 0, 0, W.s)) return rc;
+  laplace_kernel<<<(W.n_q + 3) / 4, 256, 0, W.s>>>(P.f, W.N, W.mblk, W.n_q, W.sigma, W.tq, P.beta, P.ld, P.lo);
+  tlik_reduce_kernel<<<1, 1024, 0, W.s>>>(W.tq, W.n_q, W.m, W.sc + 2);
+  grad_kernel<<<1, 1024, 0, W.s>>>(P.f, P.v, P.beta, W.N, P.g, nullptr, W.sc);
+  PPBO_LAUNCH_CHECK(W.ctx);
+  PPBO_HIP_CHECK(W.ctx, hipMemcpyAsync(W.hsc, W.sc, 3 * sizeof(double), hipMemcpyDeviceToHost, W.s));
+  PPBO_HIP_CHECK(W.ctx, hipStreamSynchronize(W.s));
+  P.fSf = W.hsc[0];
+  P.gn2 = W.hsc[1];
+  P.Tlik = W.hsc[2];
+  return 0;
+}
+
+inline double phi_of(const Vecs& P) { return 0.5 * P.fSf - P.Tlik; }  // phi = -T
+
+int carve_fit_work(ppbo_ctx* ctx, FitWork& W, Vecs* pts, int npts) {
+  const int N = W.N;
+  const size_t nn = (size_t)N * N;
+  W.H = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG, 2 * nn * sizeof(double));
+  if (!W.H) return (int)hipErrorOutOfMemory;
+  W.Linv = W.H + nn;
+  const size_t nvec = (size_t)npts * 6 + 4 + 3 + 1;
+  double* v = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SCRATCH, (nvec * N + W.n_q + 64) * sizeof(double) + 256);
+  if (!v) return (int)hipErrorOutOfMemory;
+  for (int k = 0; k < npts; ++k) {
+    pts[k].f = v; v += N; pts[k].v = v; v += N; pts[k].beta = v; v += N;
+    pts[k].ld = v; v += N; pts[k].lo = v; v += N; pts[k].g = v; v += N;
+  }
+  W.u = v; v += N; W.w = v; v += N; W.p = v; v += N; W.q = v; v += N;
+  W.rowstats = v; v += 3 * (size_t)N;
+  W.tq = v; v += W.n_q;
+  W.sc = v; v += 32;
+  W.d_info = (int*)v;
+  W.hsc = (double*)ppbo_pinned(ctx, 64 * sizeof(double));
+  if (!W.hsc) return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "pinned staging");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ppbo_laplace_terms(ppbo_ctx* ctx, const double* d_f, int N, int m, double sigma, double* d_Tlik,
+                       double* d_beta, double* d_lam_diag, double* d_lam_off, void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_REQUIRE(ctx, d_f && N > 0 && m >= 1 && sigma > 0, "arguments");
+  PPBO_REQUIRE(ctx, N % (m + 1) == 0, "N must be n_q*(m+1) (feedback_processing.py:110-130)");
+  hipStream_t s = (hipStream_t)stream;
+  const int mblk = m + 1, n_q = N / mblk;
+  double* tq = nullptr;
+  if (d_Tlik) {
+    tq = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, (size_t)n_q * sizeof(double));
+    if (!tq) return (int)hipErrorOutOfMemory;
+  }
+  laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(d_f, N, mblk, n_q, sigma, tq, d_beta, d_lam_diag, d_lam_off);
+  if (d_Tlik) tlik_reduce_kernel<<<1, 1024, 0, s>>>(tq, n_q, m, d_Tlik);
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int ppbo_T_and_grad(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_f, int N, int m, double sigma,
+                    double* h_T, double* d_grad, void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_REQUIRE(ctx, d_Sigma_inv && d_f && N > 0 && m >= 1 && sigma > 0, "arguments");
+  PPBO_REQUIRE(ctx, N % (m + 1) == 0, "N must be n_q*(m+1)");
+  hipStream_t s = (hipStream_t)stream;
+  const int mblk = m + 1, n_q = N / mblk;
+  double* v = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SCRATCH, ((size_t)2 * N + n_q + 8) * sizeof(double));
+  if (!v) return (int)hipErrorOutOfMemory;
+  double* beta = v + N;
+  double* tq = beta + N;
+  double* sc = tq + n_q;
+  if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, d_f, v, 0, 0, s)) return rc;
+  laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(d_f, N, mblk, n_q, sigma, tq, beta, nullptr, nullptr);
+  tlik_reduce_kernel<<<1, 1024, 0, s>>>(tq, n_q, m, sc + 2);
+  grad_kernel<<<1, 1024, 0, s>>>(d_f, v, beta, N, nullptr, d_grad, sc);
+  PPBO_LAUNCH_CHECK(ctx);
+  if (h_T) {
+    double h[3];
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(h, sc, sizeof(h), hipMemcpyDeviceToHost, s));
+    PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    *h_T = -0.5 * h[0] + h[2];
+  }
+  return 0;
+}
+
+int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double sigma, const double* d_f_init,
+                  const ppbo_fit_opts* opts, double* d_fMAP, ppbo_fit_stats* h_stats, void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_REQUIRE(ctx, d_Sigma_inv && d_f_init && d_fMAP, "null pointer");
+  PPBO_REQUIRE(ctx, N > 0 && m >= 1 && sigma > 0, "sizes");
+  PPBO_REQUIRE(ctx, N % (m + 1) == 0, "N must be n_q*(m+1)");
+  const double gtol = (opts && opts->gtol > 0) ? opts->gtol : 1e-4;
+  const int maxiter = (opts && opts->maxiter > 0) ? opts->maxiter : 200 * N;
+  const int verbose = opts ? opts->verbose : 0;
+
+  FitWork W{};
+  W.ctx = ctx; W.s = (hipStream_t)stream; W.Sinv = d_Sigma_inv;
+  W.N = N; W.m = m; W.mblk = m + 1; W.n_q = N / (m + 1); W.sigma = sigma;
+  Vecs pt[2];
+  if (int rc = carve_fit_work(ctx, W, pt, 2)) return rc;
+  hipStream_t s = W.s;
+  const size_t vbytes = (size_t)N * sizeof(double);
+  int cur = 0;
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(pt[cur].f, d_f_init, vbytes, hipMemcpyDeviceToDevice, s));
+  if (int rc = eval_point(W, pt[cur])) return rc;
+
+  double radius = 1.0;
+  const double rmax = 1000.0, eta = 0.15, k_easy = 0.1;
+  double lam_lb_prev = 0.0;
+  bool shrink = false, h_changed = true;
+  double st_mindiag = 0, st_gmax = 0, st_gmin = 0, st_fro = 0, st_inf = 0;
+  int it = 0, nchol = 0;
+  bool h_at_zero = false;  // H buffer currently holds the unfactorized lam=0 matrix
+
+  while (it < maxiter && std::sqrt(pt[cur].gn2) >= gtol) {
+    ++it;
+    Vecs& C = pt[cur];
+    Vecs& T = pt[cur ^ 1];
+    const double gnorm = std::sqrt(C.gn2);
+    if (h_changed) {
+      form_shifted_kernel<<<N, 256, 0, s>>>(W.Sinv, N, W.mblk, C.ld, C.lo, 0.0, W.H, W.rowstats);
+      stats_reduce_kernel<<<1, 1024, 0, s>>>(W.rowstats, N, W.sc + 8);
+      PPBO_LAUNCH_CHECK(ctx);
+      PPBO_HIP_CHECK(ctx, hipMemcpyAsync(W.hsc, W.sc + 8, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
+      PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+      st_mindiag = W.hsc[0]; st_gmax = W.hsc[1]; st_gmin = W.hsc[2];
+      st_fro = std::sqrt(W.hsc[3]); st_inf = W.hsc[4];
+      h_changed = false;
+      h_at_zero = true;
+    }
+    // ---- subproblem: min g'p + 1/2 p'Hp, |p| <= radius --------------------
+    const double hn = std::fmin(st_fro, st_inf);
+    double lb = std::fmax(0.0, std::fmax(-st_mindiag, gnorm / radius - std::fmin(st_gmax, hn)));
+    double ub = std::fmax(0.0, gnorm / radius + std::fmin(-st_gmin, hn));
+    if (shrink) lb = std::fmax(lb, lam_lb_prev);
+    double lam = (lb == 0.0) ? 0.0 : std::fmax(std::sqrt(lb * ub), lb + 0.01 * (ub - lb));
+    bool boundary = true, have_step = false;
+    double pn = 0.0, gtp = 0.0, lam_used = 0.0;
+    for (int inner = 0; inner < 80; ++inner) {
+      if (!(h_at_zero && lam == 0.0)) {
+        form_shifted_kernel<<<N, 256, 0, s>>>(W.Sinv, N, W.mblk, C.ld, C.lo, lam, W.H, nullptr);
+        PPBO_LAUNCH_CHECK(ctx);
+      }
+      h_at_zero = false;
+      ++nchol;
+      if (int rc = ppbo_potrf_async(ctx, W.H, N, N, W.d_info, s)) return rc;
+      int info = 0;
+      PPBO_HIP_CHECK(ctx, hipMemcpyAsync(&info, W.d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+      PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+      if (info != 0) {
+        lb = std::fmax(lb, lam);
+        if (ub <= lb) ub = 2.0 * lb + 1e-12;
+        lam = std::fmax(std::sqrt(lb * ub), lb + 0.01 * (ub - lb));
+        continue;
+      }
+      if (int rc = ppbo_trtri_async(ctx, W.H, N, N, W.Linv, N, s)) return rc;
+      if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, C.g, W.w, 0, 1, s)) return rc;   // w = L^-1 g
+      if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.w, W.u, 1, 1, s)) return rc;   // u = L^-T w
+      step_kernel<<<1, 1024, 0, s>>>(W.u, C.g, C.f, N, W.p, T.f, W.sc + 16);           // p = -u, fn = f + p
+      if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.p, W.q, 0, 1, s)) return rc;   // q = L^-1 p
+      if (int rc = ppbo_dot_async(ctx, W.q, W.q, N, W.sc + 18, s)) return rc;
+      PPBO_HIP_CHECK(ctx, hipMemcpyAsync(W.hsc, W.sc + 16, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+      PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+      pn = std::sqrt(W.hsc[0]);
+      gtp = W.hsc[1];
+      const double qn2 = W.hsc[2];
+      have_step = true;
+      lam_used = lam;
+      if (pn <= radius && lam == 0.0) { boundary = false; break; }
+      if (std::fabs(pn - radius) <= k_easy * radius) break;
+      double lam_new = lam + (pn * pn / qn2) * (pn - radius) / radius;
+      if (pn < radius) ub = lam; else lb = lam;
+      if (!(lb < lam_new && lam_new < ub)) lam_new = std::fmax(std::sqrt(lb * ub), lb + 0.01 * (ub - lb));
+      if (lam_new < 0.0) lam_new = 0.0;
+      if (lam_new == lam) break;
+      lam = lam_new;
+    }
+    lam_lb_prev = lb;
+    if (!have_step) break;
+    // (H + lam I) p = -g  =>  p'Hp = -g'p - lam |p|^2
+    const double pred = -0.5 * gtp + 0.5 * lam_used * pn * pn;
+    if (!(pred > 0.0)) break;
+    if (int rc = eval_point(W, T)) return rc;
+    const double rho = (phi_of(C) - phi_of(T)) / pred;
+    const double old_radius = radius;
+    if (!(rho >= 0.25)) radius *= 0.25;
+    else if (rho > 0.75 && boundary) radius = std::fmin(2.0 * radius, rmax);
+    shrink = radius < old_radius;
+    if (verbose)
+      printf("[ppbo_fit] it %d lam %.3e |p| %.3e rho %.3f radius %.3e phi %.12e |g| %.3e nchol %d\n", it, lam_used,
+             pn, rho, radius, phi_of(C), gnorm, nchol);
+    if (rho > eta) {
+      cur ^= 1;
+      h_changed = true;
+    }
+    if (radius < 1e-14) break;
+  }
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(d_fMAP, pt[cur].f, vbytes, hipMemcpyDeviceToDevice, s));
+  PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  if (h_stats) {
+    h_stats->iterations = it;
+    h_stats->n_cholesky = nchol;
+    h_stats->gradnorm = std::sqrt(pt[cur].gn2);
+    h_stats->converged = (h_stats->gradnorm < gtol) ? 1 : 0;
+    h_stats->T = -phi_of(pt[cur]);
+  }
+  return 0;
+}
+
+int ppbo_posterior(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fMAP, int N, int m, double sigma,
+                   double* d_alpha, double* d_lam_diag, double* d_lam_off, double* d_G, double* d_P, int* h_info,
+                   void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_REQUIRE(ctx, d_Sigma_inv && d_fMAP && d_alpha && d_lam_diag && d_lam_off && d_G, "null pointer");
+  PPBO_REQUIRE(ctx, N > 0 && m >= 1 && sigma > 0 && N % (m + 1) == 0, "sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const int mblk = m + 1, n_q = N / mblk;
+  const size_t nn = (size_t)N * N;
+  double* H = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG, 2 * nn * sizeof(double));
+  if (!H) return (int)hipErrorOutOfMemory;
+  double* R = H + nn;
+  if (h_info) *h_info = 0;
+  if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, d_fMAP, d_alpha, 0, 0, s)) return rc;
+  laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(d_fMAP, N, mblk, n_q, sigma, nullptr, nullptr, d_lam_diag, d_lam_off);
+  form_shifted_kernel<<<N, 256, 0, s>>>(d_Sigma_inv, N, mblk, d_lam_diag, d_lam_off, 0.0, H, nullptr);
+  PPBO_LAUNCH_CHECK(ctx);
+  int info = 0;
+  const int rc = ppbo_potrf(ctx, H, N, N, &info, stream);
+  if (h_info) *h_info = info;
+  if (rc) return rc;
+  if (int rc2 = ppbo_trtri_async(ctx, H, N, N, R, N, s)) return rc2;
+  g_build_kernel<<<dim3((N + 255) / 256, n_q), 256, 0, s>>>(R, N, mblk, d_lam_diag, d_lam_off, d_G);
+  PPBO_LAUNCH_CHECK(ctx);
+  if (d_P) {
+    GemmArgs g{};  // P = R^T R
+    g.A = R; g.lda = N; g.B = R; g.ldb = N; g.C = d_P; g.ldc = N;
+    g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0; g.klo_mode = 1; g.tri_block = 1;
+    if (int rc3 = ppbo_gemm_launch(ctx, g, 1, 0, s)) return rc3;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// Generic fp64 MFMA GEMM on the gemm64 tile engine:  C = alpha op(A) op(B) + beta C.
+// Used by the dense factorizations (SYRK/TRSM-as-GEMM updates, triangular
+// inverse products) and exposed as ppbo_dgemm for tests.
+#include "gemm_f64.h"
+#include "linalg.h"
+
+namespace {
+
+using namespace gemm64;
+
+template <int ALAY, int BLAY>
+__global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
+  extern __shared__ double lds[];
+  if (g.batch > 1) {
+    g.A += (size_t)blockIdx.y * g.strideA;
+    g.B += (size_t)blockIdx.y * g.strideB;
+    g.C += (size_t)blockIdx.y * g.strideC;
+  }
+  const int ntn = (g.N + BN - 1) / BN;
+  const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  if (g.lower_only && n0 > m0 + BM - 1) return;
+  int kbeg = 0, kend = g.K;
+  if (g.khi_mode == 1) {
+    const int e = ((m0 + BM + g.tri_block - 1) / g.tri_block) * g.tri_block;
+    kend = e < g.K ? e : g.K;
+  } else if (g.khi_mode == 2) {
+    const int e = (m0 < n0 ? m0 : n0) + BM;
+    kend = e < g.K ? e : g.K;
+  }
+  if (g.klo_mode == 1) kbeg = (m0 > n0 ? m0 : n0);
+  else if (g.klo_mode == 2) kbeg = n0;
+  double4_t acc[4][4];
+  zero_acc(acc);
+  mainloop<ALAY, BLAY>(g.A, g.lda, g.B, g.ldb, g.M, g.N, g.K, m0, n0, kbeg, kend, lds, acc);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + acc_row(i, r);
+      if (row >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + acc_col(j);
+        if (col >= g.N) continue;
+        double* c = g.C + (size_t)row * g.ldc + col;
+        double v = g.alpha * acc[i][j][r];
+        if (g.beta != 0.0) v += g.beta * (*c);
+        *c = v;
+      }
+    }
+}
+
+}  // namespace
+
+int ppbo_gemm_launch(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0) return 0;
+  const int ntm = (g.M + gemm64::BM - 1) / gemm64::BM, ntn = (g.N + gemm64::BN - 1) / gemm64::BN;
+  const size_t lds = gemm64::LDS_DOUBLES * sizeof(double);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)dgemm_kernel<KC, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dgemm_kernel<KC, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dgemm_kernel<RC, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dgemm_kernel<RC, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const dim3 grid(ntm * ntn, g.batch > 1 ? g.batch : 1);
+  if (!transA && !transB) dgemm_kernel<KC, RC><<<grid, 256, lds, s>>>(g);
+  else if (!transA && transB) dgemm_kernel<KC, KC><<<grid, 256, lds, s>>>(g);
+  else if (transA && !transB) dgemm_kernel<RC, RC><<<grid, 256, lds, s>>>(g);
+  else dgemm_kernel<RC, KC><<<grid, 256, lds, s>>>(g);
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+extern "C" int ppbo_dgemm(ppbo_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha,
+                          const double* d_A, int lda, const double* d_B, int ldb, double beta, double* d_C,
+                          int ldc, void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_REQUIRE(ctx, d_A && d_B && d_C, "null pointer");
+  PPBO_REQUIRE(ctx, M >= 0 && N >= 0 && K >= 0, "sizes");
+  GemmArgs g{};
+  g.A = d_A; g.lda = lda; g.B = d_B; g.ldb = ldb; g.C = d_C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+  g.tri_block = 1;
+  return ppbo_gemm_launch(ctx, g, transA, transB, (hipStream_t)stream);
+}

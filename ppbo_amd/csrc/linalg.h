@@ -1,0 +1,30 @@
+// Internal (non-ABI) dense linear-algebra entry points shared between .hip files.
+#pragma once
+#include "common.h"
+
+struct GemmArgs {
+  const double* A; int lda;
+  const double* B; int ldb;
+  double* C; int ldc;
+  int M, N, K;
+  double alpha, beta;
+  int lower_only;   // skip output tiles strictly above the diagonal
+  int khi_mode;     // 0: K   1: A block-lower-triangular (k < roundup(m0+128, tri_block))   2: k < min(m0,n0)+128
+  int klo_mode;     // 0: 0   1: k >= max(m0, n0)   2: k >= n0
+  int tri_block;
+  int batch;                      // grid.y; operand b lives at base + b*stride (elements); 0/1 = single
+  long long strideA, strideB, strideC;
+};
+
+// C = alpha op(A) op(B) + beta C on the fp64 MFMA engine (see gemm.hip)
+int ppbo_gemm_launch(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, hipStream_t s);
+
+// in-place lower Cholesky; d_info (device int) receives 0 or the failing 1-based column
+int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hipStream_t s);
+// d_Linv (full N x N, upper part zeroed) = inverse of lower-triangular L
+int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d_Linv, int ldi, hipStream_t s);
+// y = T x (trans=0) or y = T^T x (trans=1) for a lower-triangular (lower=1) or full N x N matrix
+int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const double* d_x, double* d_y, int trans,
+                    int lower, hipStream_t s);
+// out[0] = sum_i x_i y_i  (deterministic single-block reduction)
+int ppbo_dot_async(ppbo_ctx* ctx, const double* d_x, const double* d_y, int N, double* d_out, hipStream_t s);

@@ -1,0 +1,314 @@
+// K6: hand-written fp64 dense kernels: blocked Cholesky, triangular inverse, GEMV, dot.
+//   reference: misc.py:96-100 (pd_inverse = LAPACK posv with B = I), the Cholesky
+//   factorizations inside SciPy's trust-exact (gp_model.py:382-384).
+//
+// potrf (right-looking, NB = 64), per panel:
+//   potf2_wave   one wavefront, lane = row of the 64x64 diagonal block held in 64 fp64
+//                registers; column pivots/multipliers move with v_readlane (no LDS, no barrier)
+//   trsm_panel   one lane per row below the panel: 64-step forward substitution against
+//                the diagonal block broadcast from LDS
+//   syrk         trailing update on the fp64 MFMA engine (gemm.hip, NT form, lower tiles only)
+// trtri: 64x64 diagonal inverses (lane = column), then log2(N/64) levels of batched MFMA GEMMs
+//   X21 = -inv(L22) (L21 inv(L11)).
+// A failing pivot writes its 1-based column to *d_info; later kernels see it and return at once.
+#include "linalg.h"
+
+namespace {
+
+constexpr int NB = 64;
+
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void potf2_wave_kernel(double* __restrict__ A, int lda, int k0, int kb,
+                                                        int* __restrict__ info) {
+  if (*info != 0) return;
+  const int lane = threadIdx.x;
+  double a[NB];
+  double* row = A + (size_t)(k0 + lane) * lda + k0;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) a[c] = (lane < kb && c < kb && c <= lane) ? row[c] : ((c == lane) ? 1.0 : 0.0);
+  int fail = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const double d = lane_bcast(a[j], j);
+    if (!(d > 0.0) && fail == 0 && j < kb) fail = j + 1;  // also catches NaN
+    const double piv = sqrt(d);
+    const double lij = (lane == j) ? piv : a[j] / piv;
+    a[j] = lij;
+#pragma unroll
+    for (int k = j + 1; k < NB; ++k) {
+      const double lkj = lane_bcast(lij, k);
+      a[k] -= lij * lkj;
+    }
+  }
+  if (fail) {
+    if (lane == 0) *info = k0 + fail;
+    return;
+  }
+  if (lane < kb) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (c <= lane) row[c] = a[c];
+  }
+}
+
+// rows i in [k0+64, N): A[i, k0:k0+64] <- A[i, k0:k0+64] L_kk^-T
+__global__ __launch_bounds__(128) void trsm_panel_kernel(double* __restrict__ A, int lda, int N, int k0,
+                                                         const int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double Ls[NB * NB];
+  if (*info != 0) return;
+  for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
+    const int r = e / NB, c = e - r * NB;
+    Ls[e] = (c <= r) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int i = k0 + NB + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double* row = A + (size_t)i * lda + k0;
+  double x[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) x[c] = row[c];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    double v = x[c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) v -= x[k] * Ls[c * NB + k];
+    x[c] = v / Ls[c * NB + c];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int c = 0; c < NB; ++c) row[c] = x[c];
+}
+
+// inverse of the 64x64 diagonal blocks of lower-triangular L; lane = column of the inverse.
+// The running column lives in LDS ([r][lane], conflict free); L entries are broadcast reads.
+__global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict__ L, int ldl, int N,
+                                                        double* __restrict__ Li, int ldi) {
+  __shared__ __attribute__((aligned(16))) double Ls[NB * NB];
+  __shared__ double Ys[NB * NB];
+  const int b0 = blockIdx.x * NB;
+  const int kb = (N - b0 < NB) ? (N - b0) : NB;
+  for (int e = threadIdx.x; e < NB * NB; e += 64) {
+    const int r = e / NB, c = e - r * NB;
+    Ls[e] = (r < kb && c <= r) ? L[(size_t)(b0 + r) * ldl + b0 + c] : ((r == c) ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  for (int r = 0; r < NB; ++r) {
+    double v = (r == c) ? 1.0 : 0.0;
+    const double* lr = Ls + r * NB;
+#pragma unroll 8
+    for (int k = 0; k < r; ++k) v -= lr[k] * Ys[k * NB + c];
+    v = (r >= c) ? v / lr[r] : 0.0;
+    Ys[r * NB + c] = v;
+    if (c < kb && r < kb) Li[(size_t)(b0 + r) * ldi + b0 + c] = v;
+  }
+}
+
+// y = T x, one wavefront per row
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ T, int N, int ldt,
+                                                        const double* __restrict__ x, double* __restrict__ y,
+                                                        int lower) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const int kend = lower ? (i + 1) : N;
+  const double* row = T + (size_t)i * ldt;
+  double s = 0.0;
+  const bool vec = ((ldt & 1) == 0) && ((reinterpret_cast<uintptr_t>(T) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (vec) {
+    const int kv = kend & ~1;
+    for (int k = lane * 2; k < kv; k += 128) {
+      const double2 t = *reinterpret_cast<const double2*>(row + k);
+      const double2 xv = *reinterpret_cast<const double2*>(x + k);
+      s += t.x * xv.x + t.y * xv.y;
+    }
+    if ((kend & 1) && lane == 0) s += row[kend - 1] * x[kend - 1];
+  } else {
+    for (int k = lane; k < kend; k += 64) s += row[k] * x[k];
+  }
+  s = wave_sum(s);
+  if (lane == 0) y[i] = s;
+}
+
+// partial[split][j] = sum_{i in split, i >= (lower ? j : 0)} T[i][j] x[i]
+__global__ __launch_bounds__(256) void gemvT_partial_kernel(const double* __restrict__ T, int N, int ldt,
+                                                            const double* __restrict__ x,
+                                                            double* __restrict__ partial, int rows_per_split,
+                                                            int lower) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  int i0 = blockIdx.y * rows_per_split;
+  int i1 = i0 + rows_per_split;
+  if (i1 > N) i1 = N;
+  if (lower && i0 < j) i0 = j;
+  double s = 0.0;
+  for (int i = i0; i < i1; ++i) s += T[(size_t)i * ldt + j] * x[i];
+  partial[(size_t)blockIdx.y * N + j] = s;
+}
+
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const double* __restrict__ partial, int n_split, int N,
+                                                        double* __restrict__ y) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  double s = 0.0;
+  for (int k = 0; k < n_split; ++k) s += partial[(size_t)k * N + j];
+  y[j] = s;
+}
+
+__global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                   int N, double* __restrict__ out) {
+  __shared__ double sh[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < N; i += 1024) s += x[i] * y[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    *out = t;
+  }
+}
+
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+
+}  // namespace
+
+int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hipStream_t s) {
+  set_int_kernel<<<1, 1, 0, s>>>(d_info, 0);
+  for (int k0 = 0; k0 < N; k0 += NB) {
+    const int kb = (N - k0 < NB) ? (N - k0) : NB;
+    potf2_wave_kernel<<<1, 64, 0, s>>>(d_A, lda, k0, kb, d_info);
+    const int rest = N - k0 - NB;
+    if (rest > 0) {
+      trsm_panel_kernel<<<(rest + 127) / 128, 128, 0, s>>>(d_A, lda, N, k0, d_info);
+      GemmArgs g{};
+      g.A = d_A + (size_t)(k0 + NB) * lda + k0; g.lda = lda;
+      g.B = g.A; g.ldb = lda;
+      g.C = d_A + (size_t)(k0 + NB) * lda + (k0 + NB); g.ldc = lda;
+      g.M = rest; g.N = rest; g.K = NB; g.alpha = -1.0; g.beta = 1.0;
+      g.lower_only = 1; g.tri_block = 1;
+      if (int rc = ppbo_gemm_launch(ctx, g, 0, 1, s)) return rc;
+    }
+  }
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d_Linv, int ldi, hipStream_t s) {
+  PPBO_HIP_CHECK(ctx, hipMemsetAsync(d_Linv, 0, (size_t)N * ldi * sizeof(double), s));
+  const int nblk = (N + NB - 1) / NB;
+  trtri_diag_kernel<<<nblk, 64, 0, s>>>(d_L, ldl, N, d_Linv, ldi);
+  PPBO_LAUNCH_CHECK(ctx);
+  if (N <= NB) return 0;
+  double* Tw = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG2, (size_t)N * N / 2 * sizeof(double) + 4096);
+  if (!Tw) return (int)hipErrorOutOfMemory;
+  for (int b = NB; b < N; b *= 2) {
+    const int step = 2 * b;
+    int nfull = 0;
+    int ragged_r0 = -1, ragged_b2 = 0;
+    for (int r0 = 0; r0 + b < N; r0 += step) {
+      const int b2 = (N - r0 - b < b) ? (N - r0 - b) : b;
+      if (b2 == b) ++nfull;
+      else { ragged_r0 = r0; ragged_b2 = b2; }
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool rag = (pass == 1);
+      if (rag && ragged_r0 < 0) continue;
+      if (!rag && nfull == 0) continue;
+      const int r0 = rag ? ragged_r0 : 0;
+      const int b2 = rag ? ragged_b2 : b;
+      double* T = Tw + (rag ? (size_t)nfull * b * b : 0);
+      GemmArgs g1{};  // T = L21 inv(L11)
+      g1.A = d_L + (size_t)(r0 + b) * ldl + r0; g1.lda = ldl;
+      g1.B = d_Linv + (size_t)r0 * ldi + r0; g1.ldb = ldi;
+      g1.C = T; g1.ldc = b;
+      g1.M = b2; g1.N = b; g1.K = b; g1.alpha = 1.0; g1.beta = 0.0;
+      g1.klo_mode = 2; g1.tri_block = 1;
+      g1.batch = rag ? 1 : nfull;
+      g1.strideA = (long long)step * ldl + step; g1.strideB = (long long)step * ldi + step;
+      g1.strideC = (long long)b * b;
+      if (int rc = ppbo_gemm_launch(ctx, g1, 0, 0, s)) return rc;
+      GemmArgs g2{};  // X21 = -inv(L22) T
+      g2.A = d_Linv + (size_t)(r0 + b) * ldi + (r0 + b); g2.lda = ldi;
+      g2.B = T; g2.ldb = b;
+      g2.C = d_Linv + (size_t)(r0 + b) * ldi + r0; g2.ldc = ldi;
+      g2.M = b2; g2.N = b; g2.K = b2; g2.alpha = -1.0; g2.beta = 0.0;
+      g2.khi_mode = 1; g2.tri_block = 1;
+      g2.batch = rag ? 1 : nfull;
+      g2.strideA = (long long)step * ldi + step; g2.strideB = (long long)b * b;
+      g2.strideC = (long long)step * ldi + step;
+      if (int rc = ppbo_gemm_launch(ctx, g2, 0, 0, s)) return rc;
+    }
+  }
+  return 0;
+}
+
+int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const double* d_x, double* d_y, int trans,
+                    int lower, hipStream_t s) {
+  if (!trans) {
+    gemv_rows_kernel<<<(N + 3) / 4, 256, 0, s>>>(d_T, N, ldt, d_x, d_y, lower);
+  } else {
+    const int n_split = 32;
+    const int rows = (N + n_split - 1) / n_split;
+    double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, (size_t)n_split * N * sizeof(double));
+    if (!part) return (int)hipErrorOutOfMemory;
+    gemvT_partial_kernel<<<dim3((N + 255) / 256, n_split), 256, 0, s>>>(d_T, N, ldt, d_x, part, rows, lower);
+    sum_slabs_kernel<<<(N + 255) / 256, 256, 0, s>>>(part, n_split, N, d_y);
+  }
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int ppbo_dot_async(ppbo_ctx* ctx, const double* d_x, const double* d_y, int N, double* d_out, hipStream_t s) {
+  dot_kernel<<<1, 1024, 0, s>>>(d_x, d_y, N, d_out);
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+extern "C" {
+
+int ppbo_potrf(ppbo_ctx* ctx, double* d_A, int N, int lda, int* h_info, void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_REQUIRE(ctx, d_A && N > 0 && lda >= N, "matrix");
+  hipStream_t s = (hipStream_t)stream;
+  int* d_info = (int*)ppbo_workspace(ctx, ppbo_ctx::WS_SMALL, 4096);
+  if (!d_info) return (int)hipErrorOutOfMemory;
+  if (int rc = ppbo_potrf_async(ctx, d_A, N, lda, d_info, s)) return rc;
+  int info = 0;
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  if (h_info) *h_info = info;
+  if (info != 0) return ppbo_set_error(ctx, PPBO_ERR_NOT_PD, "matrix is not positive definite (leading minor %d)", info);
+  return 0;
+}
+
+int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int* h_info, void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_REQUIRE(ctx, d_A && d_Ainv && N > 0, "matrix");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t bytes = (size_t)N * N * sizeof(double);
+  double* L = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG, 2 * bytes);
+  if (!L) return (int)hipErrorOutOfMemory;
+  double* Li = L + (size_t)N * N;
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(L, d_A, bytes, hipMemcpyDeviceToDevice, s));
+  int info = 0;
+  if (int rc = ppbo_potrf(ctx, L, N, N, &info, stream)) {
+    if (h_info) *h_info = info;
+    return rc;
+  }
+  if (h_info) *h_info = 0;
+  if (int rc = ppbo_trtri_async(ctx, L, N, N, Li, N, s)) return rc;
+  GemmArgs g{};  // A^-1 = Linv^T Linv
+  g.A = Li; g.lda = N; g.B = Li; g.ldb = N; g.C = d_Ainv; g.ldc = N;
+  g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0; g.klo_mode = 1; g.tri_block = 1;
+  return ppbo_gemm_launch(ctx, g, 1, 0, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,495 @@
+// K2+K3+K4: batched candidate scoring (posterior mean, variance, score, argmax).
+//   reference: gp_model.py:441-461 (mu_Sigma_pred / mu_pred), called per candidate by
+//   mu_star's DE (:415-437) and per 70-point line by EI/varmax (acquisition.py:72-81,170-178).
+//
+// Posterior state (see ppbo_posterior): alpha = Sigma^-1 f_MAP, Lambda_MAP in star form,
+// G = R Lambda with R = chol(Sigma^-1 - Lambda)^-1 (block lower triangular).  For a candidate x
+//   mu(x)  = k*' alpha
+//   var(x) = sigma_f^2 - k*' A k*,  A = Sigma^-1 - Sigma^-1 P Sigma^-1  (gp_model.py:449)
+//          = sigma_f^2 + k*' Lambda k* + |G k*|^2                        (Woodbury, same operator)
+// Pass 1 (kstar_kernel, VALU): one lane = two candidates held in registers, X rows
+//   arrive through scalar loads; writes K*[N, Mc] (j-major) once and reduces mu and
+//   k*'Lambda k* in registers (no cross-lane traffic).
+// Pass 2 (quadform_kernel, fp64 MFMA): Y = G K* on 128x128 tiles, K range cut at the
+//   block-triangular edge, epilogue = column sums of Y^2 into per-row-tile slabs.
+// Pass 3 (score_kernel): slab sums -> var, score, per-block argmax; (argmax_final_kernel) -> 1 value.
+#include "gemm_f64.h"
+#include "linalg.h"
+#include "score.h"
+
+namespace {
+
+using namespace gemm64;
+
+constexpr int KS_THREADS = 256;
+constexpr int KS_CPT = 2;  // candidates per thread
+
+constexpr int KS_RJ = 32;   // X rows staged in LDS per step
+
+// DP = padded dimension (compile time): X rows are zero-padded to DP in LDS and the
+// candidate registers likewise, so the inner product loop is branch-free and fully
+// unrolled; every lane reads the same LDS address (broadcast), one ds_read_b128 per 2 dims.
+template <int KID, int DP>
+__global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
+    const double* __restrict__ X, int N, int D, KernParams p, const double* __restrict__ alpha,
+    const double* __restrict__ lam_diag, const double* __restrict__ lam_off, int mblk,
+    const double* __restrict__ Xc, int M, double* __restrict__ Kt, int ldk, double* __restrict__ mu_part,
+    double* __restrict__ t_part, int q_per_split, int n_q) {
+  __shared__ __attribute__((aligned(16))) double xs[KS_RJ * DP];
+  __shared__ double s_alpha[KS_RJ], s_ld[KS_RJ], s_lo[KS_RJ];
+  const int c0 = (blockIdx.x * KS_THREADS + threadIdx.x) * KS_CPT;
+  double xa[DP], xb[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    xa[d] = (d < D && c0 < M) ? Xc[(size_t)c0 * D + d] : 0.0;
+    xb[d] = (d < D && c0 + 1 < M) ? Xc[(size_t)(c0 + 1) * D + d] : 0.0;
+  }
+  const int j_beg = blockIdx.y * q_per_split * mblk;
+  int j_end = j_beg + q_per_split * mblk;
+  if (j_end > N) j_end = N;
+  double mu0 = 0.0, mu1 = 0.0, t0 = 0.0, t1 = 0.0, ko0 = 0.0, ko1 = 0.0;
+  const bool vec = (Kt != nullptr) && ((ldk & 1) == 0) && (c0 + 1 < M);
+  const bool has_lam = (lam_diag != nullptr);
+  int rb = 0;  // row index inside the current star block (splits start on a block edge)
+  for (int row0 = j_beg; row0 < j_end; row0 += KS_RJ) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < KS_RJ * DP; e += KS_THREADS) {
+      const int r = e / DP, d = e - r * DP;
+      const int j = row0 + r;
+      xs[e] = (j < j_end && d < D) ? X[(size_t)j * D + d] : 0.0;
+    }
+    if (threadIdx.x < KS_RJ) {
+      const int j = row0 + threadIdx.x;
+      const bool ok = j < j_end;
+      s_alpha[threadIdx.x] = ok ? alpha[j] : 0.0;
+      s_ld[threadIdx.x] = (ok && has_lam) ? lam_diag[j] : 0.0;
+      s_lo[threadIdx.x] = (ok && has_lam) ? lam_off[j] : 0.0;
+    }
+    __syncthreads();
+    const int rmax = (j_end - row0 < KS_RJ) ? (j_end - row0) : KS_RJ;
+    for (int r = 0; r < rmax; ++r) {
+      const double* __restrict__ xr = xs + r * DP;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        const double x = xr[d];
+        s0 += kern_term<KID>(x - xa[d], d, p);
+        s1 += kern_term<KID>(x - xb[d], d, p);
+      }
+      const double k0 = kern_finish<KID>(s0, p), k1 = kern_finish<KID>(s1, p);
+      if (Kt) {
+        double* dst = Kt + (size_t)(row0 + r) * ldk + c0;
+        if (vec) *reinterpret_cast<double2*>(dst) = make_double2(k0, k1);
+        else {
+          if (c0 < M) dst[0] = k0;
+          if (c0 + 1 < M) dst[1] = k1;
+        }
+      }
+      const double a = s_alpha[r];
+      mu0 += a * k0;
+      mu1 += a * k1;
+      if (has_lam) {
+        const double ld = s_ld[r];
+        if (rb == 0) {
+          ko0 = k0; ko1 = k1;
+          t0 += ld * k0 * k0;
+          t1 += ld * k1 * k1;
+        } else {
+          const double lo2 = 2.0 * s_lo[r];
+          t0 += k0 * (ld * k0 + lo2 * ko0);
+          t1 += k1 * (ld * k1 + lo2 * ko1);
+        }
+      }
+      if (++rb == mblk) rb = 0;
+    }
+  }
+  if (c0 < M) {
+    mu_part[(size_t)blockIdx.y * M + c0] = mu0;
+    if (t_part) t_part[(size_t)blockIdx.y * M + c0] = t0;
+  }
+  if (c0 + 1 < M) {
+    mu_part[(size_t)blockIdx.y * M + c0 + 1] = mu1;
+    if (t_part) t_part[(size_t)blockIdx.y * M + c0 + 1] = t1;
+  }
+}
+
+// Y = G K* ; slab[mt][c] = sum over the 128 rows of tile mt of Y[i,c]^2
+__global__ __launch_bounds__(256, 2) void quadform_kernel(const double* __restrict__ G, int N,
+                                                          const double* __restrict__ Kt, int ldk, int M,
+                                                          int tri_block, double* __restrict__ slab, int ntm,
+                                                          int ntn, int swizzle) {
+  extern __shared__ double lds[];
+  int id = blockIdx.x;
+  if (swizzle) {                       // XCD-aware: consecutive logical ids share an XCD / L2
+    const int per = gridDim.x >> 3;
+    id = (id & 7) * per + (id >> 3);
+  }
+  // row tile fastest, heaviest (largest K range) first
+  const int mt = ntm - 1 - (id % ntm), nt = id / ntm;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int e = ((m0 + BM + tri_block - 1) / tri_block) * tri_block;
+  const int kend = e < N ? e : N;
+  double4_t acc[4][4];
+  zero_acc(acc);
+  mainloop<KC, RC>(G, N, Kt, ldk, N, M, N, m0, n0, 0, kend, lds, acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  double* red = lds;  // [2][128]; mainloop ended with a barrier
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 16) red[wm * BN + wn * 64 + j * 16 + lane] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < BN) {
+    const int c = n0 + threadIdx.x;
+    if (c < M) slab[(size_t)mt * M + c] = red[threadIdx.x] + red[BN + threadIdx.x];
+  }
+}
+
+// Z = Lambda K*  (star-graph rows), Kt/Z are [N, M] with row stride ld
+__global__ void lam_apply_kernel(const double* __restrict__ Kt, int ld, int N, int M, int mblk,
+                                 const double* __restrict__ lam_diag, const double* __restrict__ lam_off,
+                                 double* __restrict__ Z) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = blockIdx.y;
+  if (c >= M) return;
+  const int i = q * mblk;
+  const double ko = Kt[(size_t)i * ld + c];
+  double zo = lam_diag[i] * ko;
+  for (int r = 1; r < mblk && i + r < N; ++r) {
+    const int j = i + r;
+    const double kj = Kt[(size_t)j * ld + c];
+    const double lo = lam_off[j];
+    Z[(size_t)j * ld + c] = lam_diag[j] * kj + lo * ko;
+    zo += lo * kj;
+  }
+  Z[(size_t)i * ld + c] = zo;
+}
+
+// prior block of one line: cov_b[g][h] = (1-s) k(x_g, x_h), diagonal (1-s) sf2 + s sf2  (gp_model.py:447)
+template <int KID>
+__global__ __launch_bounds__(256) void line_prior_kernel(const double* __restrict__ grid, int G, int D,
+                                                         KernParams p, double shrink, double* __restrict__ cov) {
+  const double* xg = grid + (size_t)blockIdx.x * G * D;
+  double* c = cov + (size_t)blockIdx.x * G * G;
+  for (int e = threadIdx.x; e < G * G; e += blockDim.x) {
+    const int g = e / G, h = e - g * G;
+    double s = 0.0;
+    for (int d = 0; d < D; ++d) s += kern_term<KID>(xg[g * D + d] - xg[h * D + d], d, p);
+    c[e] = (g == h) ? ((1.0 - shrink) * p.sf2 + shrink * p.sf2) : (1.0 - shrink) * kern_finish<KID>(s, p);
+  }
+}
+
+// One workgroup per line: Cholesky of the GxG posterior covariance in LDS, then S
+// draws f = mu + L z (lane = draw), max over the line, EI / varmax statistics.
+//   reference: acquisition.py:72-81 (EI), :170-178 (varmax).
+__global__ __launch_bounds__(256) void line_mc_kernel(const double* __restrict__ mu, const double* __restrict__ cov,
+                                                      int G, const double* __restrict__ z, int S, double mustar,
+                                                      double jitter, double* __restrict__ ei,
+                                                      double* __restrict__ varmax) {
+  extern __shared__ double sm[];
+  double* Lm = sm;                 // [G][G+1]
+  double* mus = sm + (size_t)G * (G + 1);
+  double* red = mus + G;           // [4]
+  const int ld = G + 1;
+  const double* c = cov + (size_t)blockIdx.x * G * G;
+  const double* m = mu + (size_t)blockIdx.x * G;
+  for (int e = threadIdx.x; e < G * G; e += blockDim.x) {
+    const int g = e / G, h = e - g * G;
+    // symmetrise (the two GEMM contributions are symmetric only up to rounding)
+    Lm[g * ld + h] = 0.5 * (c[g * G + h] + c[h * G + g]) + ((g == h) ? jitter : 0.0);
+  }
+  for (int g = threadIdx.x; g < G; g += blockDim.x) mus[g] = m[g];
+  __syncthreads();
+  for (int j = 0; j < G; ++j) {
+    const double d = Lm[j * ld + j];
+    const double piv = (d > 0.0) ? sqrt(d) : 0.0;     // semi-definite: drop the direction
+    __syncthreads();
+    for (int i = j + threadIdx.x; i < G; i += blockDim.x)
+      Lm[i * ld + j] = (i == j) ? piv : ((piv > 0.0) ? Lm[i * ld + j] / piv : 0.0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < (G - j - 1) * (G - j - 1); e += blockDim.x) {
+      const int a = j + 1 + e / (G - j - 1), b = j + 1 + e % (G - j - 1);
+      if (b <= a) Lm[a * ld + b] -= Lm[a * ld + j] * Lm[b * ld + j];
+    }
+    __syncthreads();
+  }
+  double sum_ei = 0.0, sum_f = 0.0, sum_f2 = 0.0;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    const double* zs = z + (size_t)s * G;
+    double fmx = -INFINITY;
+    for (int g = 0; g < G; ++g) {
+      double f = mus[g];
+      for (int h = 0; h <= g; ++h) f += Lm[g * ld + h] * zs[h];
+      fmx = fmax(fmx, f);
+    }
+    sum_ei += fmax(fmx - mustar, 0.0);
+    sum_f += fmx;
+    sum_f2 += fmx * fmx;
+  }
+  sum_ei = wave_sum(sum_ei);
+  sum_f = wave_sum(sum_f);
+  sum_f2 = wave_sum(sum_f2);
+  double* r3 = red;  // [3][4]
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { r3[w] = sum_ei; r3[4 + w] = sum_f; r3[8 + w] = sum_f2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double e = r3[0] + r3[1] + r3[2] + r3[3];
+    const double f1 = r3[4] + r3[5] + r3[6] + r3[7];
+    const double f2 = r3[8] + r3[9] + r3[10] + r3[11];
+    if (ei) ei[blockIdx.x] = e / S;
+    const double mean = f1 / S;
+    if (varmax) varmax[blockIdx.x] = f2 / S - mean * mean;
+  }
+}
+
+template <int KID>
+int launch_kstar(const ppbo_model* m, const KernParams& p, const double* d_Xc, int M, double* Kt, int ldk,
+                 double* mu_part, double* t_part, int q_per_split, int n_split, bool with_lam, hipStream_t s) {
+  dim3 grid((M + KS_THREADS * KS_CPT - 1) / (KS_THREADS * KS_CPT), n_split);
+  const int mblk = m->m + 1, n_q = (m->N + mblk - 1) / mblk;
+  const double* ld = with_lam ? m->d_lam_diag : nullptr;
+  const double* lo = with_lam ? m->d_lam_off : nullptr;
+#define KS_LAUNCH(DP)                                                                                          \
+  kstar_kernel<KID, DP><<<grid, KS_THREADS, 0, s>>>(m->d_X, m->N, m->D, p, m->d_alpha, ld, lo, mblk, d_Xc, M, \
+                                                    Kt, ldk, mu_part, with_lam ? t_part : nullptr,            \
+                                                    q_per_split, n_q)
+  if (KID == PPBO_KERNEL_CAMPHOR) KS_LAUNCH(6);
+  else if (m->D <= 4) KS_LAUNCH(4);
+  else if (m->D <= 6) KS_LAUNCH(6);
+  else if (m->D <= 8) KS_LAUNCH(8);
+  else if (m->D <= 10) KS_LAUNCH(10);
+  else if (m->D <= 12) KS_LAUNCH(12);
+  else if (m->D <= 16) KS_LAUNCH(16);
+  else if (m->D <= 20) KS_LAUNCH(20);
+  else if (m->D <= 24) KS_LAUNCH(24);
+  else if (m->D <= 32) KS_LAUNCH(32);
+  else if (m->D <= 48) KS_LAUNCH(48);
+  else KS_LAUNCH(64);
+#undef KS_LAUNCH
+  return 0;
+}
+
+int dispatch_kstar(const ppbo_model* m, const double* d_Xc, int M, double* Kt, int ldk, double* mu_part,
+                   double* t_part, int q_per_split, int n_split, bool with_lam, hipStream_t s) {
+  const KernParams p = make_kern_params(m->kernel_id, m->theta);
+  switch (m->kernel_id) {
+    case PPBO_KERNEL_SE: return launch_kstar<PPBO_KERNEL_SE>(m, p, d_Xc, M, Kt, ldk, mu_part, t_part, q_per_split, n_split, with_lam, s);
+    case PPBO_KERNEL_RQ: return launch_kstar<PPBO_KERNEL_RQ>(m, p, d_Xc, M, Kt, ldk, mu_part, t_part, q_per_split, n_split, with_lam, s);
+    default: return launch_kstar<PPBO_KERNEL_CAMPHOR>(m, p, d_Xc, M, Kt, ldk, mu_part, t_part, q_per_split, n_split, with_lam, s);
+  }
+}
+
+int check_model(ppbo_ctx* ctx, const ppbo_model* m) {
+  PPBO_REQUIRE(ctx, m != nullptr, "model");
+  PPBO_REQUIRE(ctx, m->d_X && m->d_alpha, "model X/alpha");
+  PPBO_REQUIRE(ctx, m->N > 0 && m->D > 0 && m->D <= 64 && m->m >= 1, "model sizes (D<=64)");
+  PPBO_REQUIRE(ctx, m->N % (m->m + 1) == 0, "N must be n_q*(m+1) (feedback_processing.py:110-130)");
+  PPBO_REQUIRE(ctx, m->kernel_id >= 0 && m->kernel_id <= 2, "kernel_id");
+  PPBO_REQUIRE(ctx, m->kernel_id != PPBO_KERNEL_CAMPHOR || m->D == 6, "camphor kernel needs D == 6");
+  return 0;
+}
+
+int pick_split(int M, int n_q) {
+  // enough (block, split) pairs to give every SIMD several wavefronts
+  const int blocks = (M + KS_THREADS * KS_CPT - 1) / (KS_THREADS * KS_CPT);
+  int want = (2048 + blocks - 1) / blocks;
+  if (want > n_q) want = n_q;
+  if (want > 64) want = 64;
+  if (want < 1) want = 1;
+  return want;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
+                 double mustar, double* d_mu, double* d_var, double* d_score, double* h_best_val,
+                 int64_t* h_best_idx, void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  if (int rc = check_model(ctx, model)) return rc;
+  PPBO_REQUIRE(ctx, d_Xc != nullptr && M > 0, "candidates");
+  PPBO_REQUIRE(ctx, score_kind >= 0 && score_kind <= 2, "score_kind");
+  const bool want_var = (model->d_G != nullptr);
+  PPBO_REQUIRE(ctx, want_var || (d_var == nullptr && score_kind == PPBO_SCORE_MEAN),
+               "variance / EI scores need model->d_G");
+  PPBO_REQUIRE(ctx, !want_var || (model->d_lam_diag && model->d_lam_off), "model Lambda");
+  hipStream_t s = (hipStream_t)stream;
+  const int N = model->N, mblk = model->m + 1, n_q = N / mblk;
+  const int64_t chunk_cap = 65536;
+  const int64_t n_chunks = (M + chunk_cap - 1) / chunk_cap;
+  const int ntm = (N + BM - 1) / BM;
+
+  // workspaces sized for the largest chunk
+  const int Mc_max = (int)(M < chunk_cap ? M : chunk_cap);
+  const int ldk = (Mc_max + 1) & ~1;
+  const int n_split = pick_split(Mc_max, n_q);
+  const int q_per_split = (n_q + n_split - 1) / n_split;
+  const int n_split_eff = (n_q + q_per_split - 1) / q_per_split;
+  double* Kt = nullptr;
+  if (want_var) {
+    Kt = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_KSTAR, (size_t)N * ldk * sizeof(double));
+    if (!Kt) return (int)hipErrorOutOfMemory;
+  }
+  const size_t part_doubles = (size_t)(2 * n_split_eff + ntm) * Mc_max;
+  double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_PART, part_doubles * sizeof(double));
+  if (!part) return (int)hipErrorOutOfMemory;
+  const int sblocks_max = (Mc_max + 255) / 256;
+  Best* bests = (Best*)ppbo_workspace(ctx, ppbo_ctx::WS_SMALL, (size_t)(sblocks_max + n_chunks) * sizeof(Best));
+  if (!bests) return (int)hipErrorOutOfMemory;
+  Best* chunk_best = bests + sblocks_max;
+
+  const size_t qf_lds = LDS_DOUBLES * sizeof(double);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)quadform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qf_lds);
+    attr_done = true;
+  }
+
+  for (int64_t ch = 0; ch < n_chunks; ++ch) {
+    const int64_t c_beg = ch * chunk_cap;
+    const int Mc = (int)((M - c_beg) < chunk_cap ? (M - c_beg) : chunk_cap);
+    const double* xc = d_Xc + (size_t)c_beg * model->D;
+    double* mu_part = part;
+    double* t_part = part + (size_t)n_split_eff * Mc;
+    double* slab = part + (size_t)2 * n_split_eff * Mc;
+    dispatch_kstar(model, xc, Mc, Kt, ldk, mu_part, t_part, q_per_split, n_split_eff, want_var, s);
+    PPBO_LAUNCH_CHECK(ctx);
+    if (want_var) {
+      const int ntn = (Mc + BN - 1) / BN;
+      const int grid = ntm * ntn;
+      quadform_kernel<<<grid, 256, qf_lds, s>>>(model->d_G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn,
+                                                (grid % 8 == 0 && grid >= 64) ? 1 : 0);
+      PPBO_LAUNCH_CHECK(ctx);
+    }
+    const int sblocks = (Mc + 255) / 256;
+    score_kernel<<<sblocks, 256, 0, s>>>(mu_part, n_split_eff, t_part, want_var ? slab : nullptr, ntm, Mc,
+                                         model->theta[2] * model->theta[2], score_kind, mustar,
+                                         (long long)c_beg, d_mu ? d_mu + c_beg : nullptr,
+                                         d_var ? d_var + c_beg : nullptr, d_score ? d_score + c_beg : nullptr,
+                                         bests);
+    PPBO_LAUNCH_CHECK(ctx);
+    argmax_final_kernel<<<1, 256, 0, s>>>(bests, sblocks, chunk_best + ch);
+    PPBO_LAUNCH_CHECK(ctx);
+  }
+  if (int rc = merge_chunk_bests(ctx, chunk_best, (int)n_chunks, h_best_val, h_best_idx, s)) return rc;
+  return 0;
+}
+
+int ppbo_predict_cov(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int M, double shrink,
+                     double* d_mu, double* d_cov, void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  if (int rc = check_model(ctx, model)) return rc;
+  PPBO_REQUIRE(ctx, d_Xc && d_cov && M > 0 && M <= 16384, "candidates (M <= 16384 for a full covariance)");
+  PPBO_REQUIRE(ctx, model->d_G && model->d_lam_diag && model->d_lam_off, "model G/Lambda");
+  hipStream_t s = (hipStream_t)stream;
+  const int N = model->N, mblk = model->m + 1, n_q = N / mblk;
+  const int ld = (M + 1) & ~1;
+  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_KSTAR, (size_t)3 * N * ld * sizeof(double));
+  if (!ws) return (int)hipErrorOutOfMemory;
+  double* Kt = ws;
+  double* Z = ws + (size_t)N * ld;
+  double* Y = ws + (size_t)2 * N * ld;
+  const int n_split = pick_split(M, n_q);
+  const int q_per_split = (n_q + n_split - 1) / n_split;
+  const int n_split_eff = (n_q + q_per_split - 1) / q_per_split;
+  double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_PART, (size_t)n_split_eff * M * sizeof(double));
+  if (!part) return (int)hipErrorOutOfMemory;
+  dispatch_kstar(model, d_Xc, M, Kt, ld, part, nullptr, q_per_split, n_split_eff, false, s);
+  PPBO_LAUNCH_CHECK(ctx);
+  if (d_mu) {
+    score_kernel<<<(M + 255) / 256, 256, 0, s>>>(part, n_split_eff, nullptr, nullptr, 0, M, 0.0, PPBO_SCORE_MEAN,
+                                                 0.0, 0, d_mu, nullptr, nullptr, nullptr);
+    PPBO_LAUNCH_CHECK(ctx);
+  }
+  // prior block with the reference's shrinkage (gp_model.py:447)
+  if (int rc = ppbo_gram(ctx, model->kernel_id, d_Xc, M, model->D, model->theta, shrink, d_cov, stream)) return rc;
+  // + K*' Lambda K*
+  lam_apply_kernel<<<dim3((M + 127) / 128, n_q), 128, 0, s>>>(Kt, ld, N, M, mblk, model->d_lam_diag,
+                                                              model->d_lam_off, Z);
+  PPBO_LAUNCH_CHECK(ctx);
+  GemmArgs g{};
+  g.A = Kt; g.lda = ld; g.B = Z; g.ldb = ld; g.C = d_cov; g.ldc = M;
+  g.M = M; g.N = M; g.K = N; g.alpha = 1.0; g.beta = 1.0; g.tri_block = 1;
+  if (int rc = ppbo_gemm_launch(ctx, g, 1, 0, s)) return rc;
+  // + (G K*)' (G K*)
+  GemmArgs y{};
+  y.A = model->d_G; y.lda = N; y.B = Kt; y.ldb = ld; y.C = Y; y.ldc = ld;
+  y.M = N; y.N = M; y.K = N; y.alpha = 1.0; y.beta = 0.0; y.khi_mode = 1; y.tri_block = mblk;
+  if (int rc = ppbo_gemm_launch(ctx, y, 0, 0, s)) return rc;
+  GemmArgs c{};
+  c.A = Y; c.lda = ld; c.B = Y; c.ldb = ld; c.C = d_cov; c.ldc = M;
+  c.M = M; c.N = M; c.K = N; c.alpha = 1.0; c.beta = 1.0; c.tri_block = 1;
+  return ppbo_gemm_launch(ctx, c, 1, 0, s);
+}
+
+int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, int B, int G, double shrink,
+                  const double* d_z, int S, double mustar, double jitter, double* d_ei, double* d_varmax,
+                  void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  if (int rc = check_model(ctx, model)) return rc;
+  PPBO_REQUIRE(ctx, d_grid && d_z && B > 0 && G > 0 && G <= 128 && S > 0, "line arguments (G <= 128)");
+  PPBO_REQUIRE(ctx, model->d_G && model->d_lam_diag && model->d_lam_off, "model G/Lambda");
+  hipStream_t s = (hipStream_t)stream;
+  const int N = model->N, mblk = model->m + 1, n_q = N / mblk, D = model->D;
+  const KernParams p = make_kern_params(model->kernel_id, model->theta);
+  const int Bc_max = (B < 512) ? B : 512;
+  const int ld = ((Bc_max * G) + 1) & ~1;
+  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_KSTAR, (size_t)3 * N * ld * sizeof(double));
+  if (!ws) return (int)hipErrorOutOfMemory;
+  double* Kt = ws;
+  double* Z = ws + (size_t)N * ld;
+  double* Y = ws + (size_t)2 * N * ld;
+  const int n_split = pick_split(Bc_max * G, n_q);
+  const int q_per_split = (n_q + n_split - 1) / n_split;
+  const int n_split_eff = (n_q + q_per_split - 1) / q_per_split;
+  double* part = (double*)ppbo_workspace(
+      ctx, ppbo_ctx::WS_PART, ((size_t)(n_split_eff + 1) * Bc_max * G + (size_t)Bc_max * G * G) * sizeof(double));
+  if (!part) return (int)hipErrorOutOfMemory;
+  double* mu = part + (size_t)n_split_eff * Bc_max * G;
+  double* cov = mu + (size_t)Bc_max * G;
+  const size_t mc_lds = ((size_t)G * (G + 1) + G + 16) * sizeof(double);
+  for (int b0 = 0; b0 < B; b0 += Bc_max) {
+    const int Bc = (B - b0 < Bc_max) ? (B - b0) : Bc_max;
+    const int M = Bc * G;
+    const double* xg = d_grid + (size_t)b0 * G * D;
+    dispatch_kstar(model, xg, M, Kt, ld, part, nullptr, q_per_split, n_split_eff, false, s);
+    score_kernel<<<(M + 255) / 256, 256, 0, s>>>(part, n_split_eff, nullptr, nullptr, 0, M, 0.0, PPBO_SCORE_MEAN, 0.0,
+                                                 0, mu, nullptr, nullptr, nullptr);
+    switch (model->kernel_id) {
+      case PPBO_KERNEL_SE: line_prior_kernel<PPBO_KERNEL_SE><<<Bc, 256, 0, s>>>(xg, G, D, p, shrink, cov); break;
+      case PPBO_KERNEL_RQ: line_prior_kernel<PPBO_KERNEL_RQ><<<Bc, 256, 0, s>>>(xg, G, D, p, shrink, cov); break;
+      default: line_prior_kernel<PPBO_KERNEL_CAMPHOR><<<Bc, 256, 0, s>>>(xg, G, D, p, shrink, cov); break;
+    }
+    lam_apply_kernel<<<dim3((M + 127) / 128, n_q), 128, 0, s>>>(Kt, ld, N, M, mblk, model->d_lam_diag,
+                                                                model->d_lam_off, Z);
+    PPBO_LAUNCH_CHECK(ctx);
+    GemmArgs y{};  // Y = G K*
+    y.A = model->d_G; y.lda = N; y.B = Kt; y.ldb = ld; y.C = Y; y.ldc = ld;
+    y.M = N; y.N = M; y.K = N; y.alpha = 1.0; y.beta = 0.0; y.khi_mode = 1; y.tri_block = mblk;
+    if (int rc = ppbo_gemm_launch(ctx, y, 0, 0, s)) return rc;
+    GemmArgs c1{};  // cov_b += K*_b' Z_b   (batched over lines)
+    c1.A = Kt; c1.lda = ld; c1.B = Z; c1.ldb = ld; c1.C = cov; c1.ldc = G;
+    c1.M = G; c1.N = G; c1.K = N; c1.alpha = 1.0; c1.beta = 1.0; c1.tri_block = 1;
+    c1.batch = Bc; c1.strideA = G; c1.strideB = G; c1.strideC = (long long)G * G;
+    if (int rc = ppbo_gemm_launch(ctx, c1, 1, 0, s)) return rc;
+    GemmArgs c2 = c1;  // cov_b += Y_b' Y_b
+    c2.A = Y; c2.B = Y;
+    if (int rc = ppbo_gemm_launch(ctx, c2, 1, 0, s)) return rc;
+    line_mc_kernel<<<Bc, 256, mc_lds, s>>>(mu, cov, G, d_z, S, mustar, jitter, d_ei ? d_ei + b0 : nullptr,
+                                           d_varmax ? d_varmax + b0 : nullptr);
+    PPBO_LAUNCH_CHECK(ctx);
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,324 @@
+// K7/K8/K9: random Fourier features of the SE kernel.
+//   reference: random_fourier_sampler.py:45-58 (phiVec/update_phi_X), :166,170 (phi(x)^T omega),
+//              :106-122 (S, S_grad, S_hessian -- the Hessian is diagonal).
+// Phi is [F, N] row-major (feature-major, as the reference stores phi_X).
+//   rff_project: 64x64 output tiles, both operand panels staged transposed in LDS, 4x4
+//                micro-tiles per lane, epilogue sqrt(2 sf^2/F) cos(. + b_f); HBM-write bound
+//                (8 F N bytes), full 512-byte row-segment stores.
+//   rff_score  : one lane = two candidates in registers, W/b/omega rows broadcast from LDS,
+//                features split across blockIdx.y into partial slabs; Phi(Xc) never exists.
+//   rff_terms  : f = Phi^T omega (split GEMV), per-query likelihood weights (one wavefront per
+//                query), then one wavefront per feature row for S_grad / diag(S_hessian).
+#include "linalg.h"
+#include "score.h"
+
+namespace {
+
+constexpr int TS = 64;
+constexpr double INV_SQRT_4PI = 0.28209479177387814347;
+
+__device__ __forceinline__ void stage_T(const double* __restrict__ X, int n, int D, int r0, double* __restrict__ dstT) {
+  for (int e = threadIdx.x; e < TS * D; e += blockDim.x) {
+    const int r = e / D, d = e - r * D;
+    const int gr = r0 + r;
+    dstT[d * TS + r] = (gr < n) ? X[(size_t)gr * D + d] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void rff_project_kernel(const double* __restrict__ X, int N, int D,
+                                                          const double* __restrict__ W, int F,
+                                                          const double* __restrict__ b, double scale,
+                                                          double* __restrict__ Phi) {
+  extern __shared__ double smem[];
+  double* WT = smem;                    // [D][64] features
+  double* XT = smem + (size_t)D * TS;   // [D][64] data rows
+  const int f0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
+  stage_T(W, F, D, f0, WT);
+  stage_T(X, N, D, n0, XT);
+  __syncthreads();
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double s[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[a][c] = 0.0;
+  for (int d = 0; d < D; ++d) {
+    double wa[4], xb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wa[a] = WT[d * TS + ty * 4 + a];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xb[c] = XT[d * TS + tx * 4 + c];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[a][c] += wa[a] * xb[c];
+  }
+  const bool vec_ok = ((N & 1) == 0) && ((reinterpret_cast<uintptr_t>(Phi) & 15) == 0);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int f = f0 + ty * 4 + a;
+    if (f >= F) continue;
+    const double bf = b[f];
+    double v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = scale * cos(s[a][c] + bf);
+    const int n = n0 + tx * 4;
+    double* dst = Phi + (size_t)f * N + n;
+    if (vec_ok && n + 3 < N) {
+      *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
+      *reinterpret_cast<double2*>(dst + 2) = make_double2(v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (n + c < N) dst[c] = v[c];
+    }
+  }
+}
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_RF = 32;  // feature rows staged per step
+
+template <int DP>
+__global__ __launch_bounds__(RS_THREADS) void rff_score_kernel(const double* __restrict__ Xc, int M, int D,
+                                                               const double* __restrict__ W, int F,
+                                                               const double* __restrict__ b,
+                                                               const double* __restrict__ omega, double scale,
+                                                               int f_per_split, double* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) double ws[RS_RF * DP];
+  __shared__ double s_b[RS_RF], s_om[RS_RF];
+  const int c0 = (blockIdx.x * RS_THREADS + threadIdx.x) * 2;
+  double xa[DP], xb[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    xa[d] = (d < D && c0 < M) ? Xc[(size_t)c0 * D + d] : 0.0;
+    xb[d] = (d < D && c0 + 1 < M) ? Xc[(size_t)(c0 + 1) * D + d] : 0.0;
+  }
+  const int f_beg = blockIdx.y * f_per_split;
+  int f_end = f_beg + f_per_split;
+  if (f_end > F) f_end = F;
+  double a0 = 0.0, a1 = 0.0;
+  for (int r0 = f_beg; r0 < f_end; r0 += RS_RF) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < RS_RF * DP; e += RS_THREADS) {
+      const int r = e / DP, d = e - r * DP;
+      const int f = r0 + r;
+      ws[e] = (f < f_end && d < D) ? W[(size_t)f * D + d] : 0.0;
+    }
+    if (threadIdx.x < RS_RF) {
+      const int f = r0 + threadIdx.x;
+      s_b[threadIdx.x] = (f < f_end) ? b[f] : 0.0;
+      s_om[threadIdx.x] = (f < f_end) ? omega[f] : 0.0;   // zero weight kills padded rows
+    }
+    __syncthreads();
+    const int rmax = (f_end - r0 < RS_RF) ? (f_end - r0) : RS_RF;
+    for (int r = 0; r < rmax; ++r) {
+      const double* __restrict__ wr = ws + r * DP;
+      double s0 = s_b[r], s1 = s_b[r];
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        const double w = wr[d];
+        s0 += w * xa[d];
+        s1 += w * xb[d];
+      }
+      const double om = s_om[r];
+      a0 += om * cos(s0);
+      a1 += om * cos(s1);
+    }
+  }
+  if (c0 < M) part[(size_t)blockIdx.y * M + c0] = scale * a0;
+  if (c0 + 1 < M) part[(size_t)blockIdx.y * M + c0 + 1] = scale * a1;
+}
+
+// partial[split][n] = sum_{f in split} Phi[f][n] omega[f]
+__global__ __launch_bounds__(256) void phiT_omega_kernel(const double* __restrict__ Phi, int F, int N,
+                                                         const double* __restrict__ omega, int f_per_split,
+                                                         double* __restrict__ partial) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int f0 = blockIdx.y * f_per_split;
+  int f1 = f0 + f_per_split;
+  if (f1 > F) f1 = F;
+  double s = 0.0;
+  for (int f = f0; f < f1; ++f) s += Phi[(size_t)f * N + n] * omega[f];
+  partial[(size_t)blockIdx.y * N + n] = s;
+}
+
+__global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict__ partial, int n_split, int N,
+                                                        double* __restrict__ y) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  double s = 0.0;
+  for (int k = 0; k < n_split; ++k) s += partial[(size_t)k * N + j];
+  y[j] = s;
+}
+
+// per query: tq = sum_j Phi(Delta_j/sqrt2); a_j = phi2(Delta_j)/(sigma m); h_j = -1/2 Delta_j phi2(Delta_j)/(m sigma^2)
+__global__ __launch_bounds__(256) void rff_weights_kernel(const double* __restrict__ f, int N, int mblk, int n_q,
+                                                          double sigma, double* __restrict__ tq,
+                                                          double* __restrict__ a, double* __restrict__ h) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n_q) return;
+  const int m = mblk - 1, i = q * mblk;
+  const double f0 = f[i];
+  double sphi = 0.0;
+  for (int r = 1 + lane; r <= m; r += 64) {
+    const int j = i + r;
+    const double delta = (f[j] - f0) / sigma;
+    sphi += 0.5 * erfc(-0.5 * delta);
+    const double p2 = INV_SQRT_4PI * exp(-0.25 * (delta * delta));
+    a[j] = p2 / (sigma * (double)m);
+    h[j] = -0.5 * delta * p2 / ((double)m * sigma * sigma);
+  }
+  sphi = wave_sum(sphi);
+  if (lane == 0) { tq[q] = sphi; a[i] = 0.0; h[i] = 0.0; }
+}
+
+// one wavefront per feature row: grad_f = -omega_f - sum_n dPhi a_n ; hdiag_f = -1 - sum_n dPhi^2 h_n
+__global__ __launch_bounds__(256) void rff_rows_kernel(const double* __restrict__ Phi, int F, int N, int mblk,
+                                                       const double* __restrict__ omega,
+                                                       const double* __restrict__ a, const double* __restrict__ h,
+                                                       double* __restrict__ grad, double* __restrict__ hdiag) {
+  const int lane = threadIdx.x & 63;
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= F) return;
+  const double* row = Phi + (size_t)f * N;
+  double sg = 0.0, sh = 0.0;
+  for (int n = lane; n < N; n += 64) {
+    const int o = (n / mblk) * mblk;
+    const double dphi = row[n] - row[o];
+    sg += dphi * a[n];
+    sh += dphi * dphi * h[n];
+  }
+  sg = wave_sum(sg);
+  sh = wave_sum(sh);
+  if (lane == 0) {
+    if (grad) grad[f] = -omega[f] - sg;
+    if (hdiag) hdiag[f] = -1.0 - sh;
+  }
+}
+
+// out[0] = -1/2 omega.omega - (1/m) sum tq
+__global__ __launch_bounds__(1024) void rff_S_kernel(const double* __restrict__ omega, int F,
+                                                     const double* __restrict__ tq, int n_q, int m,
+                                                     double* __restrict__ out) {
+  __shared__ double sh[2][16];
+  double a = 0.0, t = 0.0;
+  for (int i = threadIdx.x; i < F; i += 1024) a += omega[i] * omega[i];
+  for (int i = threadIdx.x; i < n_q; i += 1024) t += tq[i];
+  a = wave_sum(a);
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0.0, st = 0.0;
+    for (int w = 0; w < 16; ++w) { sa += sh[0][w]; st += sh[1][w]; }
+    *out = -0.5 * sa - st / (double)m;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ppbo_rff_project(ppbo_ctx* ctx, const double* d_X, int N, int D, const double* d_W, int F,
+                     const double* d_b, double sigma_f, double* d_Phi, void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_REQUIRE(ctx, d_X && d_W && d_b && d_Phi, "null pointer");
+  PPBO_REQUIRE(ctx, N > 0 && D > 0 && D <= 256 && F > 0, "sizes");
+  const double scale = std::sqrt(2.0 * sigma_f * sigma_f / (double)F);
+  dim3 grid((N + TS - 1) / TS, (F + TS - 1) / TS);
+  const size_t lds = (size_t)2 * D * TS * sizeof(double);
+  rff_project_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(d_X, N, D, d_W, F, d_b, scale, d_Phi);
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const double* d_W, int F,
+                   const double* d_b, double sigma_f, const double* d_omega, double* d_score,
+                   double* h_best_val, int64_t* h_best_idx, void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_REQUIRE(ctx, d_Xc && d_W && d_b && d_omega, "null pointer");
+  PPBO_REQUIRE(ctx, M > 0 && D > 0 && D <= 64 && F > 0, "sizes (D<=64)");
+  hipStream_t s = (hipStream_t)stream;
+  const double scale = std::sqrt(2.0 * sigma_f * sigma_f / (double)F);
+  const int64_t chunk_cap = 65536;
+  const int64_t n_chunks = (M + chunk_cap - 1) / chunk_cap;
+  const int Mc_max = (int)(M < chunk_cap ? M : chunk_cap);
+  const int cblocks = (Mc_max + RS_THREADS * 2 - 1) / (RS_THREADS * 2);
+  int n_split = (2048 + cblocks - 1) / cblocks;
+  if (n_split > (F + RS_RF - 1) / RS_RF) n_split = (F + RS_RF - 1) / RS_RF;
+  if (n_split > 64) n_split = 64;
+  if (n_split < 1) n_split = 1;
+  int f_per_split = (F + n_split - 1) / n_split;
+  f_per_split = ((f_per_split + RS_RF - 1) / RS_RF) * RS_RF;
+  n_split = (F + f_per_split - 1) / f_per_split;
+  double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_PART, (size_t)n_split * Mc_max * sizeof(double));
+  if (!part) return (int)hipErrorOutOfMemory;
+  const int sblocks_max = (Mc_max + 255) / 256;
+  Best* bests = (Best*)ppbo_workspace(ctx, ppbo_ctx::WS_SMALL, (size_t)(sblocks_max + n_chunks) * sizeof(Best));
+  if (!bests) return (int)hipErrorOutOfMemory;
+  Best* chunk_best = bests + sblocks_max;
+  for (int64_t ch = 0; ch < n_chunks; ++ch) {
+    const int64_t c_beg = ch * chunk_cap;
+    const int Mc = (int)((M - c_beg) < chunk_cap ? (M - c_beg) : chunk_cap);
+    const double* xc = d_Xc + (size_t)c_beg * D;
+    dim3 grid((Mc + RS_THREADS * 2 - 1) / (RS_THREADS * 2), n_split);
+#define RS_LAUNCH(DP) \
+  rff_score_kernel<DP><<<grid, RS_THREADS, 0, s>>>(xc, Mc, D, d_W, F, d_b, d_omega, scale, f_per_split, part)
+    if (D <= 4) RS_LAUNCH(4);
+    else if (D <= 6) RS_LAUNCH(6);
+    else if (D <= 8) RS_LAUNCH(8);
+    else if (D <= 10) RS_LAUNCH(10);
+    else if (D <= 12) RS_LAUNCH(12);
+    else if (D <= 16) RS_LAUNCH(16);
+    else if (D <= 20) RS_LAUNCH(20);
+    else if (D <= 24) RS_LAUNCH(24);
+    else if (D <= 32) RS_LAUNCH(32);
+    else if (D <= 48) RS_LAUNCH(48);
+    else RS_LAUNCH(64);
+#undef RS_LAUNCH
+    PPBO_LAUNCH_CHECK(ctx);
+    const int sblocks = (Mc + 255) / 256;
+    score_kernel<<<sblocks, 256, 0, s>>>(part, n_split, nullptr, nullptr, 0, Mc, 0.0, PPBO_SCORE_MEAN, 0.0,
+                                         (long long)c_beg, nullptr, nullptr, d_score ? d_score + c_beg : nullptr,
+                                         bests);
+    argmax_final_kernel<<<1, 256, 0, s>>>(bests, sblocks, chunk_best + ch);
+    PPBO_LAUNCH_CHECK(ctx);
+  }
+  return merge_chunk_bests(ctx, chunk_best, (int)n_chunks, h_best_val, h_best_idx, s);
+}
+
+int ppbo_rff_terms(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, double sigma,
+                   const double* d_omega, double* h_S, double* d_grad, double* d_hdiag, void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_REQUIRE(ctx, d_Phi && d_omega, "null pointer");
+  PPBO_REQUIRE(ctx, F > 0 && N > 0 && m >= 1 && sigma > 0 && N % (m + 1) == 0, "sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const int mblk = m + 1, n_q = N / mblk;
+  const int n_split = 32;
+  const int f_per_split = (F + n_split - 1) / n_split;
+  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, ((size_t)(n_split + 3) * N + n_q + 8) * sizeof(double));
+  if (!ws) return (int)hipErrorOutOfMemory;
+  double* part = ws;
+  double* f = ws + (size_t)n_split * N;
+  double* a = f + N;
+  double* h = a + N;
+  double* tq = h + N;
+  double* sc = tq + n_q;
+  phiT_omega_kernel<<<dim3((N + 255) / 256, n_split), 256, 0, s>>>(d_Phi, F, N, d_omega, f_per_split, part);
+  sum_parts_kernel<<<(N + 255) / 256, 256, 0, s>>>(part, n_split, N, f);
+  rff_weights_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(f, N, mblk, n_q, sigma, tq, a, h);
+  if (d_grad || d_hdiag)
+    rff_rows_kernel<<<(F + 3) / 4, 256, 0, s>>>(d_Phi, F, N, mblk, d_omega, a, h, d_grad, d_hdiag);
+  PPBO_LAUNCH_CHECK(ctx);
+  if (h_S) {
+    rff_S_kernel<<<1, 1024, 0, s>>>(d_omega, F, tq, n_q, m, sc);
+    PPBO_LAUNCH_CHECK(ctx);
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(h_S, sc, sizeof(double), hipMemcpyDeviceToHost, s));
+    PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+"""Thin Python layer over the C-ABI: torch-ROCm tensors own the device buffers,
+every computation is a call into libppbo_hip.so.  No NumPy math, no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import KERNEL_IDS, SCORE_MEAN, SCORE_POINTWISE_EI, SCORE_VARIANCE, PPBO_ERR_NOT_PD  # noqa: F401
+
+SHRINKAGE = 1e-6  # COVARIANCE_SHRINKAGE of the reference (gp_model.py:26)
+
+
+class NotPositiveDefinite(RuntimeError):
+    def __init__(self, msg, info=0):
+        super().__init__(msg)
+        self.info = info
+
+
+@dataclass
+class Posterior:
+    """Device-resident posterior state consumed by predict / predict_cov / line_acq."""
+    kernel: str
+    theta: tuple
+    m: int
+    X: torch.Tensor          # [N, D]
+    alpha: torch.Tensor      # [N]   Sigma^-1 f_MAP
+    lam_diag: torch.Tensor   # [N]   Lambda_MAP (star form)
+    lam_off: torch.Tensor    # [N]
+    G: torch.Tensor | None   # [N, N] R Lambda
+    P: torch.Tensor | None = None  # posterior covariance (optional)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    """One ppbo_ctx bound to one GPU."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ppbo_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        ctx = C.c_void_p()
+        rc = self.lib.ppbo_ctx_create(device, C.byref(ctx))
+        if rc != 0:
+            raise RuntimeError(f"ppbo_ctx_create failed with code {rc}")
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.ppbo_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers -------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _err(self):
+        buf = C.create_string_buffer(512)
+        self.lib.ppbo_last_error(self.ctx, buf, 512)
+        return buf.value.decode(errors="replace")
+
+    def _check(self, rc, what, info=0):
+        if rc == 0:
+            return
+        if rc == PPBO_ERR_NOT_PD:
+            raise NotPositiveDefinite(f"{what}: {self._err()}", info)
+        raise RuntimeError(f"{what} failed (code {rc}): {self._err()}")
+
+    def dev(self, a, dtype=torch.float64):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=self.device)
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float64, device=self.device)
+
+    @staticmethod
+    def _theta(theta):
+        return (C.c_double * 3)(float(theta[0]), float(theta[1]), float(theta[2]))
+
+    def _model(self, post: Posterior, with_var=True):
+        N, D = post.X.shape
+        md = _lib.Model()
+        md.kernel_id = KERNEL_IDS[post.kernel]
+        md.N, md.D, md.m = N, D, post.m
+        md.theta = self._theta(post.theta)
+        md.d_X = post.X.data_ptr()
+        md.d_alpha = post.alpha.data_ptr()
+        md.d_lam_diag = post.lam_diag.data_ptr() if post.lam_diag is not None else 0
+        md.d_lam_off = post.lam_off.data_ptr() if post.lam_off is not None else 0
+        md.d_G = post.G.data_ptr() if (with_var and post.G is not None) else 0
+        return md
+
+    # ---- K1 / K2 --------------------------------------------------------
+    def gram(self, X, theta, kernel="SE_kernel", shrink=SHRINKAGE):
+        X = self.dev(X)
+        N, D = X.shape
+        S = self.empty(N, N)
+        rc = self.lib.ppbo_gram(self.ctx, KERNEL_IDS[kernel], _ptr(X), N, D, self._theta(theta), shrink, _ptr(S),
+                                self._stream())
+        self._check(rc, "ppbo_gram")
+        return S
+
+    def cross_cov(self, X1, X2, theta, kernel="SE_kernel"):
+        X1, X2 = self.dev(X1), self.dev(X2)
+        n1, D = X1.shape
+        n2 = X2.shape[0]
+        K = self.empty(n1, n2)
+        rc = self.lib.ppbo_cross_cov(self.ctx, KERNEL_IDS[kernel], _ptr(X1), n1, _ptr(X2), n2, D, self._theta(theta),
+                                     _ptr(K), n2, self._stream())
+        self._check(rc, "ppbo_cross_cov")
+        return K
+
+    # ---- K6 ----------------------------------------------------------------
+    def potrf_(self, A):
+        """In-place lower Cholesky of a square device tensor."""
+        N = A.shape[0]
+        info = C.c_int(0)
+        rc = self.lib.ppbo_potrf(self.ctx, _ptr(A), N, A.stride(0), C.byref(info), self._stream())
+        self._check(rc, "ppbo_potrf", info.value)
+        return A
+
+    def pd_inverse(self, A):
+        A = self.dev(A)
+        N = A.shape[0]
+        out = self.empty(N, N)
+        info = C.c_int(0)
+        rc = self.lib.ppbo_pd_inverse(self.ctx, _ptr(A), N, _ptr(out), C.byref(info), self._stream())
+        self._check(rc, "ppbo_pd_inverse", info.value)
+        return out
+
+    def dgemm(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, C_out=None):
+        A, B = self.dev(A), self.dev(B)
+        M = A.shape[1] if transA else A.shape[0]
+        K = A.shape[0] if transA else A.shape[1]
+        Nn = B.shape[0] if transB else B.shape[1]
+        Cc = C_out if C_out is not None else self.empty(M, Nn)
+        rc = self.lib.ppbo_dgemm(self.ctx, int(transA), int(transB), M, Nn, K, alpha, _ptr(A), A.stride(0), _ptr(B),
+                                 B.stride(0), beta, _ptr(Cc), Cc.stride(0), self._stream())
+        self._check(rc, "ppbo_dgemm")
+        return Cc
+
+    # ---- K5 / fit -------------------------------------------------------------
+    def laplace_terms(self, f, m, sigma):
+        f = self.dev(f).reshape(-1)
+        N = f.numel()
+        T = self.empty(1)
+        beta, ld, lo = self.empty(N), self.empty(N), self.empty(N)
+        rc = self.lib.ppbo_laplace_terms(self.ctx, _ptr(f), N, m, float(sigma), _ptr(T), _ptr(beta), _ptr(ld),
+                                         _ptr(lo), self._stream())
+        self._check(rc, "ppbo_laplace_terms")
+        return float(T.item()), beta, ld, lo
+
+    def T_and_grad(self, Sigma_inv, f, m, sigma):
+        f = self.dev(f).reshape(-1)
+        N = f.numel()
+        grad = self.empty(N)
+        T = C.c_double(0.0)
+        rc = self.lib.ppbo_T_and_grad(self.ctx, _ptr(Sigma_inv), _ptr(f), N, m, float(sigma), C.byref(T), _ptr(grad),
+                                      self._stream())
+        self._check(rc, "ppbo_T_and_grad")
+        return T.value, grad
+
+    def fit_fmap(self, Sigma_inv, f_init, m, sigma, gtol=1e-4, maxiter=0, verbose=False):
+        f0 = self.dev(f_init).reshape(-1)
+        N = f0.numel()
+        out = self.empty(N)
+        opts = _lib.FitOpts(float(gtol), int(maxiter), int(bool(verbose)))
+        st = _lib.FitStats()
+        rc = self.lib.ppbo_fit_fmap(self.ctx, _ptr(Sigma_inv), N, m, float(sigma), _ptr(f0), C.byref(opts), _ptr(out),
+                                    C.byref(st), self._stream())
+        self._check(rc, "ppbo_fit_fmap")
+        stats = dict(iterations=st.iterations, n_cholesky=st.n_cholesky, converged=bool(st.converged), T=st.T,
+                     gradnorm=st.gradnorm)
+        return out, stats
+
+    def posterior(self, X, theta, kernel, Sigma_inv, fMAP, m, want_P=False) -> Posterior:
+        X = self.dev(X)
+        f = self.dev(fMAP).reshape(-1)
+        N = f.numel()
+        alpha, ld, lo = self.empty(N), self.empty(N), self.empty(N)
+        G = self.empty(N, N)
+        P = self.empty(N, N) if want_P else None
+        info = C.c_int(0)
+        rc = self.lib.ppbo_posterior(self.ctx, _ptr(Sigma_inv), _ptr(f), N, m, float(theta[0]), _ptr(alpha), _ptr(ld),
+                                     _ptr(lo), _ptr(G), _ptr(P), C.byref(info), self._stream())
+        self._check(rc, "ppbo_posterior", info.value)
+        return Posterior(kernel, tuple(float(t) for t in theta), m, X, alpha, ld, lo, G, P)
+
+    # ---- prediction ---------------------------------------------------------------
+    def predict(self, post: Posterior, Xc, score=SCORE_MEAN, mustar=0.0, want_mu=True, want_var=True,
+                want_score=False, want_best=True):
+        Xc = self.dev(Xc)
+        M = Xc.shape[0]
+        with_var = want_var or score != SCORE_MEAN
+        md = self._model(post, with_var)
+        mu = self.empty(M) if want_mu else None
+        var = self.empty(M) if (want_var and with_var) else None
+        sc = self.empty(M) if want_score else None
+        bv, bi = C.c_double(0.0), C.c_int64(-1)
+        rc = self.lib.ppbo_predict(self.ctx, C.byref(md), _ptr(Xc), M, int(score), float(mustar), _ptr(mu), _ptr(var),
+                                   _ptr(sc), C.byref(bv) if want_best else None, C.byref(bi) if want_best else None,
+                                   self._stream())
+        self._check(rc, "ppbo_predict")
+        return dict(mu=mu, var=var, score=sc, best_val=bv.value, best_idx=bi.value)
+
+    def predict_cov(self, post: Posterior, Xc, shrink=SHRINKAGE):
+        Xc = self.dev(Xc)
+        M = Xc.shape[0]
+        md = self._model(post, True)
+        mu, cov = self.empty(M), self.empty(M, M)
+        rc = self.lib.ppbo_predict_cov(self.ctx, C.byref(md), _ptr(Xc), M, float(shrink), _ptr(mu), _ptr(cov),
+                                       self._stream())
+        self._check(rc, "ppbo_predict_cov")
+        return mu, cov
+
+    def line_acq(self, post: Posterior, grid, z, mustar, shrink=SHRINKAGE, jitter=0.0):
+        grid = self.dev(grid)
+        B, G, _ = grid.shape
+        z = self.dev(z)
+        S = z.shape[0]
+        md = self._model(post, True)
+        ei, vm = self.empty(B), self.empty(B)
+        rc = self.lib.ppbo_line_acq(self.ctx, C.byref(md), _ptr(grid), B, G, float(shrink), _ptr(z), S, float(mustar),
+                                    float(jitter), _ptr(ei), _ptr(vm), self._stream())
+        self._check(rc, "ppbo_line_acq")
+        return ei, vm
+
+    # ---- RFF -------------------------------------------------------------------------
+    def rff_project(self, X, W, b, sigma_f):
+        X, W, b = self.dev(X), self.dev(W), self.dev(b).reshape(-1)
+        N, D = X.shape
+        F = W.shape[0]
+        Phi = self.empty(F, N)
+        rc = self.lib.ppbo_rff_project(self.ctx, _ptr(X), N, D, _ptr(W), F, _ptr(b), float(sigma_f), _ptr(Phi),
+                                       self._stream())
+        self._check(rc, "ppbo_rff_project")
+        return Phi
+
+    def rff_score(self, Xc, W, b, sigma_f, omega, want_score=True):
+        Xc, W, b, omega = self.dev(Xc), self.dev(W), self.dev(b).reshape(-1), self.dev(omega).reshape(-1)
+        M, D = Xc.shape
+        F = W.shape[0]
+        sc = self.empty(M) if want_score else None
+        bv, bi = C.c_double(0.0), C.c_int64(-1)
+        rc = self.lib.ppbo_rff_score(self.ctx, _ptr(Xc), M, D, _ptr(W), F, _ptr(b), float(sigma_f), _ptr(omega),
+                                     _ptr(sc), C.byref(bv), C.byref(bi), self._stream())
+        self._check(rc, "ppbo_rff_score")
+        return sc, bv.value, bi.value
+
+    def rff_terms(self, Phi, omega, m, sigma):
+        Phi, omega = self.dev(Phi), self.dev(omega).reshape(-1)
+        F, N = Phi.shape
+        g, h = self.empty(F), self.empty(F)
+        S = C.c_double(0.0)
+        rc = self.lib.ppbo_rff_terms(self.ctx, _ptr(Phi), F, N, m, float(sigma), _ptr(omega), C.byref(S), _ptr(g),
+                                     _ptr(h), self._stream())
+        self._check(rc, "ppbo_rff_terms")
+        return S.value, g, h
+
+
+_default = {}
+
+
+def get_engine(device: int = 0) -> Engine:
+    if device not in _default:
+        _default[device] = Engine(device)
+    return _default[device]

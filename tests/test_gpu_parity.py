@@ -1,0 +1,316 @@
+"""GPU parity tests: every C-ABI entry point against the CPU oracle and the golden
+vectors produced by the reference.  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import golden_names
+from oracle import ppbo_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ALL = golden_names()
+FITTED = [n for n in ("smoke", "rq", "cam_small", "c2", "c4", "c3", "c5") if n in ALL]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test needs a GPU; the HIP path has no CPU fallback")
+    from ppbo_amd.engine import get_engine
+    return get_engine(0)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, np.max(np.abs(b)))
+
+
+# ---------------------------------------------------------------- dense engine
+@pytest.mark.parametrize("shape", [(128, 128, 16), (130, 75, 33), (256, 384, 64), (70, 70, 2048), (513, 129, 257)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_dgemm(eng, shape, ta, tb):
+    M, N, K = shape
+    rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((N, K) if tb else (K, N))
+    C0 = rng.standard_normal((M, N))
+    ref = 1.5 * (A.T if ta else A) @ (B.T if tb else B) - 0.5 * C0
+    Cd = eng.dev(C0.copy())
+    out = eng.dgemm(A, B, bool(ta), bool(tb), alpha=1.5, beta=-0.5, C_out=Cd)
+    assert rel(host(out), ref) < 1e-13
+
+
+def test_dgemm_mfma_layout_is_not_transposed(eng):
+    """A = I with an asymmetric B catches a swapped C/D register map."""
+    n = 128
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n)
+    out = host(eng.dgemm(np.eye(n), B))
+    assert np.array_equal(out, B)
+
+
+@pytest.mark.parametrize("N", [64, 100, 200, 512, 650, 1031])
+def test_potrf_and_inverse(eng, N):
+    rng = np.random.default_rng(N)
+    Q = rng.standard_normal((N, N))
+    A = Q @ Q.T + N * np.eye(N)
+    L = np.tril(host(eng.potrf_(eng.dev(A.copy()))))
+    assert rel(L, np.linalg.cholesky(A)) < 1e-12
+    Ai = host(eng.pd_inverse(A))
+    assert np.abs(Ai @ A - np.eye(N)).max() < 1e-10
+    assert np.abs(Ai - Ai.T).max() <= 1e-12 * np.abs(Ai).max()
+
+
+def test_potrf_reports_not_pd(eng):
+    from ppbo_amd.engine import NotPositiveDefinite
+    N = 200
+    A = np.eye(N)
+    A[150, 150] = -1.0
+    with pytest.raises(NotPositiveDefinite) as ei:
+        eng.potrf_(eng.dev(A))
+    assert ei.value.info == 151
+
+
+# ---------------------------------------------------------------- K1 / K2
+@pytest.mark.parametrize("name", ALL)
+def test_gram_vs_reference_golden(eng, golden, name):
+    g = golden(name)
+    S = host(eng.gram(g["X"], g["theta"], str(g["kernel"])))
+    c = g["Sigma_corner"].shape[0]
+    assert rel(S[:c, :c], g["Sigma_corner"]) < 1e-12
+    assert rel(S.sum(axis=1), g["Sigma_rowsum"]) < 1e-12
+    assert rel(S[g["Sigma_ii"], g["Sigma_jj"]], g["Sigma_samples"]) < 1e-12
+    assert np.array_equal(S, S.T)
+    if int(g["N"]) <= 1024:
+        assert rel(S, orc.gram(g["X"], g["theta"], str(g["kernel"]))) < 1e-12
+
+
+@pytest.mark.parametrize("kernel,D", [("SE_kernel", 5), ("RQ_kernel", 7), ("camphor_copper_kernel", 6)])
+@pytest.mark.parametrize("n1,n2", [(1, 1), (3, 130), (200, 77), (129, 64)])
+def test_cross_cov_ragged(eng, kernel, D, n1, n2):
+    rng = np.random.default_rng(n1 * 1000 + n2)
+    X1, X2 = rng.random((n1, D)), rng.random((n2, D))
+    th = [0.05, 0.31, 0.7]
+    K = host(eng.cross_cov(X1, X2, th, kernel))
+    assert rel(K, orc.cross_cov(X1, X2, th, kernel)) < 1e-12
+
+
+def test_gram_odd_sizes(eng):
+    rng = np.random.default_rng(3)
+    for N, D in [(1, 2), (63, 3), (65, 4), (257, 9)]:
+        X = rng.random((N, D))
+        S = host(eng.gram(X, [0.1, 0.4, 1.3], "SE_kernel"))
+        assert rel(S, orc.gram(X, [0.1, 0.4, 1.3], "SE_kernel")) < 1e-12
+
+
+# ---------------------------------------------------------------- K5
+@pytest.mark.parametrize("name", ALL)
+def test_laplace_terms_vs_reference_golden(eng, golden, name):
+    g = golden(name)
+    m, sig = int(g["m"]), float(g["theta"][0])
+    for k in range(g["lap_f"].shape[0]):
+        T, beta, ld, lo = eng.laplace_terms(g["lap_f"][k], m, sig)
+        assert abs(T - g["lap_Tlik"][k]) <= 1e-12 * max(1.0, abs(g["lap_Tlik"][k]))
+        assert np.abs(host(beta) - g["lap_beta"][k]).max() <= 1e-12 * max(1.0, np.abs(g["lap_beta"][k]).max())
+        scale = max(1e-300, np.abs(g["lap_diag"][k]).max())
+        assert np.abs(host(ld) - g["lap_diag"][k]).max() <= 1e-12 * scale
+        assert np.abs(host(lo) - g["lap_off"][k]).max() <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("m", [1, 5, 25, 31, 63, 100])
+def test_laplace_terms_general_m(eng, m):
+    rng = np.random.default_rng(m)
+    n_q = 7
+    f = rng.standard_normal(n_q * (m + 1)) * 0.2
+    T, beta, ld, lo = eng.laplace_terms(f, m, 0.07)
+    assert abs(T - (-orc.sum_phi0(f, m, 0.07).sum() / m)) < 1e-12
+    assert np.abs(host(beta) - orc.beta_vector(f, m, 0.07)).max() < 1e-11
+    d0, o0 = orc.lambda_compact(f, m, 0.07)
+    assert np.abs(host(ld) - d0).max() <= 1e-12 * np.abs(d0).max()
+    assert np.abs(host(lo) - o0).max() <= 1e-12 * np.abs(d0).max()
+
+
+# ---------------------------------------------------------------- fit
+def _sinv(eng, g):
+    S = eng.gram(g["X"], g["theta"], str(g["kernel"]))
+    return S, eng.pd_inverse(S)
+
+
+@pytest.mark.parametrize("name", FITTED)
+def test_T_and_grad(eng, golden, name):
+    g = golden(name)
+    m, sig = int(g["m"]), float(g["theta"][0])
+    _, Sinv = _sinv(eng, g)
+    Sinv_h = host(Sinv)
+    for k in range(g["lap_f"].shape[0]):
+        f = g["lap_f"][k]
+        T, grad = eng.T_and_grad(Sinv, f, m, sig)
+        assert abs(T - g["lap_T"][k]) <= 1e-7 * max(1.0, abs(g["lap_T"][k]))
+        gscale = max(np.abs(Sinv_h @ f).max(), 1e-300)
+        assert np.abs(host(grad) - g["lap_grad"][k]).max() <= 1e-6 * gscale + 1e-9
+
+
+@pytest.mark.parametrize("name", FITTED)
+def test_fit_fmap_vs_reference(eng, golden, name):
+    g = golden(name)
+    m, sig = int(g["m"]), float(g["theta"][0])
+    _, Sinv = _sinv(eng, g)
+    fmap, st = eng.fit_fmap(Sinv, g["f_init"], m, sig, gtol=1e-6)
+    f = host(fmap)
+    # reference-evaluated gradient norm must not exceed the reference's own (two-level parity)
+    _, grad = eng.T_and_grad(Sinv, f, m, sig)
+    gn = np.linalg.norm(host(grad))
+    assert gn <= max(float(g["gradnorm_fMAP"]), 2e-6)
+    # distance: 1e-5 max|f| plus the reference's own Newton gap |P g_ref| (it stops at gtol 1e-4)
+    post = eng.posterior(g["X"], g["theta"], str(g["kernel"]), Sinv, g["fMAP"], m, want_P=True)
+    _, gref = eng.T_and_grad(Sinv, g["fMAP"], m, sig)
+    ref_gap = np.abs(host(post.P) @ host(gref)).max()
+    assert np.abs(f - g["fMAP"]).max() <= 1e-5 * np.abs(g["fMAP"]).max() + 1.5 * ref_gap
+    assert st["T"] >= float(g["T_fMAP"]) - 1e-7 * max(1.0, abs(float(g["T_fMAP"])))
+
+
+# ---------------------------------------------------------------- predict
+def _posterior(eng, g, want_P=False):
+    _, Sinv = _sinv(eng, g)
+    return eng.posterior(g["X"], g["theta"], str(g["kernel"]), Sinv, g["fMAP"], int(g["m"]), want_P=want_P), Sinv
+
+
+@pytest.mark.parametrize("name", FITTED)
+def test_predict_mean_var_vs_reference(eng, golden, name):
+    from ppbo_amd.engine import SCORE_MEAN
+    g = golden(name)
+    post, _ = _posterior(eng, g)
+    out = eng.predict(post, g["Xc"], score=SCORE_MEAN, want_score=True)
+    mu, var = host(out["mu"]), host(out["var"])
+    sf2 = float(g["theta"][2]) ** 2
+    assert rel(mu, g["mu"]) < 1e-6                       # north_star: 1e-5
+    assert np.abs(var - g["var"]).max() <= 1e-6 * sf2    # north_star: 1e-5 relative
+    assert rel(host(post.alpha), g["alpha"]) < 1e-6
+    assert out["best_idx"] == int(np.argmax(host(out["score"])))
+    assert out["best_val"] == host(out["score"]).max()
+    one = eng.predict(post, g["Xc"][:16], want_var=False)
+    assert rel(host(one["mu"]), g["mu_pred16"]) < 1e-6
+
+
+@pytest.mark.parametrize("name", [n for n in FITTED if n != "c5"])
+def test_posterior_covariance_vs_reference(eng, golden, name):
+    g = golden(name)
+    post, _ = _posterior(eng, g, want_P=True)
+    P = host(post.P)
+    c = g["P_corner"].shape[0]
+    scale = np.abs(g["P_diag"]).max()
+    assert np.abs(np.diag(P) - g["P_diag"]).max() <= 1e-6 * scale
+    assert np.abs(P[:c, :c] - g["P_corner"]).max() <= 1e-6 * scale
+
+
+@pytest.mark.parametrize("name", FITTED)
+def test_predict_cov_line_vs_reference(eng, golden, name):
+    g = golden(name)
+    post, _ = _posterior(eng, g)
+    mu, cov = eng.predict_cov(post, g["line_grid"])
+    sf2 = float(g["theta"][2]) ** 2
+    assert rel(host(mu), g["line_mu"]) < 1e-6
+    assert np.abs(host(cov) - g["line_cov"]).max() <= 1e-6 * sf2
+
+
+@pytest.mark.parametrize("name", [n for n in ("smoke", "c2", "c3") if n in ALL])
+def test_line_acq_matches_oracle_with_same_draws(eng, golden, name):
+    g = golden(name)
+    post, _ = _posterior(eng, g)
+    rng = np.random.default_rng(11)
+    D = int(g["D"])
+    B, G, S = 5, 70, 150
+    al = np.linspace(0.005, 0.995, G)
+    grids = []
+    for b in range(B):
+        xi = np.zeros(D); xi[b % D] = 1.0
+        x = rng.random(D); x[b % D] = 0.0
+        grids.append(orc.line_grid(xi, x, al))
+    grids[0] = g["line_grid"]
+    grid = np.stack(grids)
+    z = rng.standard_normal((S, G))
+    sf2 = float(g["theta"][2]) ** 2
+    mustar = float(g["line_mustar"])
+    jit = 1e-9 * sf2
+    ei, vm = eng.line_acq(post, grid, z, mustar, jitter=jit)
+    ei, vm = host(ei), host(vm)
+    for b in range(B):
+        mu_b, cov_b = eng.predict_cov(post, grid[b])
+        e0 = orc.line_ei(host(mu_b), host(cov_b), z, mustar, jitter=jit)
+        v0 = orc.line_varmax(host(mu_b), host(cov_b), z, jitter=jit)
+        assert abs(ei[b] - e0) <= 1e-6 * max(abs(e0), 1e-3 * np.sqrt(sf2))
+        assert abs(vm[b] - v0) <= 1e-5 * max(abs(v0), 1e-6 * sf2)
+    # line 0 is the reference's own grid: statistical agreement with its Monte Carlo value
+    zz = rng.standard_normal((4000, G))
+    e_big, _ = eng.line_acq(post, grid[:1], zz, mustar, jitter=jit)
+    smp = orc.line_samples(g["line_mu"], g["line_cov"], zz, jit).max(axis=1)
+    se = np.std(np.maximum(smp - mustar, 0)) * np.sqrt(2 / 4000)
+    assert abs(float(host(e_big)[0]) - float(g["line_ei_ref4000"])) <= 4 * se + 1e-12
+
+
+def test_argmax_first_occurrence_and_scores(eng, golden):
+    from ppbo_amd.engine import SCORE_POINTWISE_EI, SCORE_VARIANCE
+    g = golden("smoke")
+    post, _ = _posterior(eng, g)
+    Xc = np.concatenate([g["Xc"], g["Xc"]])      # every score appears twice -> first index must win
+    out = eng.predict(post, Xc, want_score=True)
+    assert out["best_idx"] == int(np.argmax(host(out["score"]))) < g["Xc"].shape[0]
+    mustar = float(np.max(g["mu"]))
+    ei = eng.predict(post, g["Xc"], score=SCORE_POINTWISE_EI, mustar=mustar, want_score=True)
+    want = orc.pointwise_ei(host(ei["mu"]), host(ei["var"]), mustar)
+    assert np.abs(host(ei["score"]) - want).max() <= 1e-10 * max(1e-12, np.abs(want).max())
+    assert ei["best_idx"] == int(np.argmax(host(ei["score"])))
+    vs = eng.predict(post, g["Xc"], score=SCORE_VARIANCE, want_score=True)
+    assert np.array_equal(host(vs["score"]), host(vs["var"]))
+
+
+# ---------------------------------------------------------------- RFF
+@pytest.mark.parametrize("name", [n for n in ("smoke", "c2", "c3") if n in ALL])
+def test_rff_vs_reference(eng, golden, name):
+    g = golden(name)
+    m, sig, sf = int(g["m"]), float(g["theta"][0]), float(g["theta"][2])
+    Phi = eng.rff_project(g["X"], g["rff_W"], g["rff_b"], sf)
+    Ph = host(Phi)
+    fc, c = g["rff_Phi_corner"].shape
+    assert rel(Ph[:fc, :c], g["rff_Phi_corner"]) < 1e-11
+    assert rel(Ph.sum(axis=1), g["rff_Phi_rowsum"]) < 1e-10
+    assert rel(Ph.sum(axis=0), g["rff_Phi_colsum"]) < 1e-10
+    S, gr, hd = eng.rff_terms(Phi, g["rff_omega"], m, sig)
+    assert abs(S - float(g["rff_S"])) <= 1e-10 * abs(float(g["rff_S"]))
+    assert rel(host(gr), g["rff_Sgrad"]) < 1e-9
+    assert rel(host(hd), g["rff_Shdiag"]) < 1e-9
+    sc, bv, bi = eng.rff_score(g["Xc"], g["rff_W"], g["rff_b"], sf, g["rff_omega"])
+    assert rel(host(sc), g["rff_scores"]) < 1e-9
+    assert bi == int(np.argmax(host(sc))) and bv == host(sc).max()
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE config C3)
+@pytest.mark.skipif("c3" not in ALL, reason="c3 fixture missing")
+def test_full_size_c3_properties(eng, golden):
+    """N=2048, D=20, M=65536: chunked scoring equals per-slice scoring, argmax equals
+    np.argmax of the returned scores, and a random subsample matches the oracle."""
+    from ppbo_amd.engine import SCORE_POINTWISE_EI
+    g = golden("c3")
+    post, Sinv = _posterior(eng, g)
+    M = 65536
+    Xc = np.random.default_rng(1).random((M, int(g["D"])))
+    mustar = float(np.max(g["mu"]))
+    full = eng.predict(post, Xc, score=SCORE_POINTWISE_EI, mustar=mustar, want_score=True)
+    sc = host(full["score"])
+    assert full["best_idx"] == int(np.argmax(sc)) and full["best_val"] == sc.max()
+    part = eng.predict(post, Xc[30000:31000], score=SCORE_POINTWISE_EI, mustar=mustar, want_score=True)
+    # independent of how the candidate set is tiled / split (only the partial-sum grouping differs)
+    assert np.allclose(host(part["mu"]), host(full["mu"])[30000:31000], rtol=0, atol=1e-12)
+    assert np.allclose(host(part["var"]), host(full["var"])[30000:31000], rtol=0, atol=1e-12)
+    idx = np.random.default_rng(2).choice(M, 256, replace=False)
+    Sinv_h = host(Sinv)
+    P = orc.posterior_covariance(Sinv_h, g["fMAP"], int(g["m"]), float(g["theta"][0]))
+    lam = orc.lambda_dense(g["fMAP"], int(g["m"]), float(g["theta"][0]))
+    A = orc.variance_operator(Sinv_h, P, faithful=False, lam=lam)
+    mu0, var0 = orc.predict_mean_var(Xc[idx], g["X"], g["theta"], Sinv_h @ g["fMAP"], A)
+    sf2 = float(g["theta"][2]) ** 2
+    assert rel(host(full["mu"])[idx], mu0) < 1e-6
+    assert np.abs(host(full["var"])[idx] - var0).max() <= 1e-6 * sf2
