@@ -8,6 +8,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch ships its own libamdhip64.so; it must be in the process BEFORE libppbo_hip.so is
+# dlopen'ed so both resolve to the same HIP runtime (device pointers are per-runtime).
+import torch  # noqa: F401  (plumbing: device memory and streams)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libppbo_hip.so")
 
