@@ -48,6 +48,15 @@ int ppbo_ctx_destroy(ppbo_ctx* ctx);
 /* copies the last error text of this ctx into buf (NUL terminated) */
 int ppbo_last_error(ppbo_ctx* ctx, char* buf, size_t n);
 
+/* ---- per-kernel event timing (the reference only prints time.time() deltas when verbose,
+ * src/gp_model.py:110-132).  When enabled, the named hot kernels are bracketed
+ * by hipEvents on the caller's stream; ppbo_profile_read synchronises those events and
+ * returns the accumulated duration and launch count since the last reset.
+ * names: "gram", "kstar", "quadform", "score", "rff_project", "rff_score", "potrf". */
+int ppbo_profile_enable(ppbo_ctx* ctx, int on);
+int ppbo_profile_reset(ppbo_ctx* ctx);
+int ppbo_profile_read(ppbo_ctx* ctx, const char* name, double* h_total_ms, int* h_count);
+
 /* ---- K1: Gram matrix with the closed-form shrinkage --------------------
  * replaces GPModel.create_Gramian (src/gp_model.py:147-151) =
  * kernel(X,X,theta) (src/kernels.py:19-53) + regularize_covariance

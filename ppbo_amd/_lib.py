@@ -44,6 +44,9 @@ SIGNATURES = {
     "ppbo_ctx_create": [_i, C.POINTER(_vp)],
     "ppbo_ctx_destroy": [_vp],
     "ppbo_last_error": [_vp, C.c_char_p, C.c_size_t],
+    "ppbo_profile_enable": [_vp, _i],
+    "ppbo_profile_reset": [_vp],
+    "ppbo_profile_read": [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(_i)],
     "ppbo_gram": [_vp, _i, _vp, _i, _i, _dp3, _d, _vp, _vp],
     "ppbo_cross_cov": [_vp, _i, _vp, _i, _vp, _i, _i, _dp3, _vp, _i, _vp],
     "ppbo_potrf": [_vp, _vp, _i, _i, C.POINTER(_i), _vp],

@@ -72,7 +72,45 @@ int ppbo_ctx_destroy(ppbo_ctx* ctx) {
   for (int i = 0; i < ppbo_ctx::WS_COUNT; ++i)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  for (int i = 0; i < ppbo_ctx::PF_COUNT; ++i)
+    for (auto& pr : ctx->pf_events[i]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   delete ctx;
+  return 0;
+}
+
+static int pf_slot(const char* name) {
+  static const char* names[] = {"gram", "kstar", "quadform", "score", "rff_project", "rff_score", "potrf"};
+  for (int i = 0; i < ppbo_ctx::PF_COUNT; ++i)
+    if (std::strcmp(name, names[i]) == 0) return i;
+  return -1;
+}
+
+int ppbo_profile_enable(ppbo_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  ctx->profiling = (on != 0);
+  return 0;
+}
+
+int ppbo_profile_reset(ppbo_ctx* ctx) {
+  if (!ctx) return -1;
+  for (int i = 0; i < ppbo_ctx::PF_COUNT; ++i) ctx->pf_used[i] = 0;
+  return 0;
+}
+
+int ppbo_profile_read(ppbo_ctx* ctx, const char* name, double* h_total_ms, int* h_count) {
+  if (!ctx || !name) return -1;
+  const int slot = pf_slot(name);
+  if (slot < 0) return ppbo_set_error(ctx, -1, "unknown profile name %s", name);
+  double tot = 0.0;
+  for (size_t i = 0; i < ctx->pf_used[slot]; ++i) {
+    auto& pr = ctx->pf_events[slot][i];
+    PPBO_HIP_CHECK(ctx, hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    PPBO_HIP_CHECK(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+    tot += ms;
+  }
+  if (h_total_ms) *h_total_ms = tot;
+  if (h_count) *h_count = (int)ctx->pf_used[slot];
   return 0;
 }
 

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/ppbo_hip.h"
 
@@ -22,6 +24,29 @@ struct ppbo_ctx {
   size_t ws_bytes[WS_COUNT] = {};
   void* pinned = nullptr;  // small pinned host staging buffer
   size_t pinned_bytes = 0;
+  // optional per-kernel event timing
+  bool profiling = false;
+  enum { PF_GRAM = 0, PF_KSTAR, PF_QUADFORM, PF_SCORE, PF_RFF_PROJECT, PF_RFF_SCORE, PF_POTRF, PF_COUNT };
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pf_events[PF_COUNT];
+  size_t pf_used[PF_COUNT] = {};
+};
+
+// RAII bracket: records two events around a launch when profiling is on
+struct PpboProfScope {
+  ppbo_ctx* ctx; int slot; hipStream_t s; hipEvent_t stop = nullptr;
+  PpboProfScope(ppbo_ctx* c, int slot_, hipStream_t s_) : ctx(c), slot(slot_), s(s_) {
+    if (!ctx || !ctx->profiling) return;
+    auto& v = ctx->pf_events[slot];
+    if (ctx->pf_used[slot] == v.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      v.emplace_back(a, b);
+    }
+    auto& pr = v[ctx->pf_used[slot]++];
+    (void)hipEventRecord(pr.first, s);
+    stop = pr.second;
+  }
+  ~PpboProfScope() { if (stop) (void)hipEventRecord(stop, s); }
 };
 
 int ppbo_set_error(ppbo_ctx* ctx, int code, const char* fmt, ...);

@@ -176,6 +176,7 @@ int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, con
   const int nblk = nt * (nt + 1) / 2;
   const size_t lds = ((size_t)2 * D * TS + (size_t)TS * TP) * sizeof(double);
   hipStream_t s = (hipStream_t)stream;
+  PpboProfScope pf(ctx, ppbo_ctx::PF_GRAM, s);
   switch (kernel_id) {
     case PPBO_KERNEL_SE: gram_kernel<PPBO_KERNEL_SE><<<nblk, 256, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt); break;
     case PPBO_KERNEL_RQ: gram_kernel<PPBO_KERNEL_RQ><<<nblk, 256, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt); break;

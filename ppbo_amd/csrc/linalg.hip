@@ -181,6 +181,7 @@ __global__ void set_int_kernel(int* p, int v) { *p = v; }
 }  // namespace
 
 int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hipStream_t s) {
+  PpboProfScope pf(ctx, ppbo_ctx::PF_POTRF, s);
   set_int_kernel<<<1, 1, 0, s>>>(d_info, 0);
   for (int k0 = 0; k0 < N; k0 += NB) {
     const int kb = (N - k0 < NB) ? (N - k0) : NB;

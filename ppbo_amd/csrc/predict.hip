@@ -362,16 +362,21 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
     double* mu_part = part;
     double* t_part = part + (size_t)n_split_eff * Mc;
     double* slab = part + (size_t)2 * n_split_eff * Mc;
-    dispatch_kstar(model, xc, Mc, Kt, ldk, mu_part, t_part, q_per_split, n_split_eff, want_var, s);
+    {
+      PpboProfScope pf(ctx, ppbo_ctx::PF_KSTAR, s);
+      dispatch_kstar(model, xc, Mc, Kt, ldk, mu_part, t_part, q_per_split, n_split_eff, want_var, s);
+    }
     PPBO_LAUNCH_CHECK(ctx);
     if (want_var) {
       const int ntn = (Mc + BN - 1) / BN;
       const int grid = ntm * ntn;
+      PpboProfScope pf(ctx, ppbo_ctx::PF_QUADFORM, s);
       quadform_kernel<<<grid, 256, qf_lds, s>>>(model->d_G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn,
                                                 (grid % 8 == 0 && grid >= 64) ? 1 : 0);
       PPBO_LAUNCH_CHECK(ctx);
     }
     const int sblocks = (Mc + 255) / 256;
+    PpboProfScope pfs(ctx, ppbo_ctx::PF_SCORE, s);
     score_kernel<<<sblocks, 256, 0, s>>>(mu_part, n_split_eff, t_part, want_var ? slab : nullptr, ntm, Mc,
                                          model->theta[2] * model->theta[2], score_kind, mustar,
                                          (long long)c_beg, d_mu ? d_mu + c_beg : nullptr,

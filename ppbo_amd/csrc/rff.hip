@@ -229,6 +229,7 @@ int ppbo_rff_project(ppbo_ctx* ctx, const double* d_X, int N, int D, const doubl
   const double scale = std::sqrt(2.0 * sigma_f * sigma_f / (double)F);
   dim3 grid((N + TS - 1) / TS, (F + TS - 1) / TS);
   const size_t lds = (size_t)2 * D * TS * sizeof(double);
+  PpboProfScope pf(ctx, ppbo_ctx::PF_RFF_PROJECT, (hipStream_t)stream);
   rff_project_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(d_X, N, D, d_W, F, d_b, scale, d_Phi);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
@@ -264,6 +265,7 @@ int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const do
     const int Mc = (int)((M - c_beg) < chunk_cap ? (M - c_beg) : chunk_cap);
     const double* xc = d_Xc + (size_t)c_beg * D;
     dim3 grid((Mc + RS_THREADS * 2 - 1) / (RS_THREADS * 2), n_split);
+    PpboProfScope pf(ctx, ppbo_ctx::PF_RFF_SCORE, s);
 #define RS_LAUNCH(DP) \
   rff_score_kernel<DP><<<grid, RS_THREADS, 0, s>>>(xc, Mc, D, d_W, F, d_b, d_omega, scale, f_per_split, part)
     if (D <= 4) RS_LAUNCH(4);

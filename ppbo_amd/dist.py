@@ -1,0 +1,55 @@
+"""Multi-GPU candidate search: one process per GPU, candidates sharded by contiguous row
+blocks, model state replicated (every rank fits the same deterministic model, so there is
+no data-path collective), and ONE collective per search: an all-gather of the 16-byte
+(best score, global index) record, combined with np.argmax tie-breaking (lowest index).
+
+The reference has no distributed code; this replaces the sequential differential-evolution
+search of mu_star (gp_model.py:415-437) for sharded candidate sets.  Backend "nccl" is RCCL
+on ROCm (xGMI); "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(M: int, rank: int, world: int):
+    """Contiguous row block [lo, hi) of rank `rank` (first M % world ranks get one extra row)."""
+    base, rem = divmod(M, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def combine_best(vals: torch.Tensor, idxs: torch.Tensor):
+    """Max value, ties -> smallest global index; entries with idx < 0 are empty."""
+    best_v, best_i = None, -1
+    for v, i in zip(vals.tolist(), idxs.tolist()):
+        i = int(i)
+        if i < 0 or v != v:
+            continue
+        if best_i < 0 or v > best_v or (v == best_v and i < best_i):
+            best_v, best_i = v, i
+    return (best_v if best_i >= 0 else float("nan")), best_i
+
+
+def allgather_argmax(local_val: float, local_global_idx: int, device=None, group=None):
+    """All ranks get the global (value, index).  Index travels as int64, value as float64."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return float(local_val), int(local_global_idx)
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
+    rec_v = torch.tensor([float(local_val)], dtype=torch.float64, device=dev)
+    rec_i = torch.tensor([int(local_global_idx)], dtype=torch.int64, device=dev)
+    out_v = torch.empty(world, dtype=torch.float64, device=dev)
+    out_i = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out_v, rec_v, group=group)
+    dist.all_gather_into_tensor(out_i, rec_i, group=group)
+    return combine_best(out_v.cpu(), out_i.cpu())
+
+
+def sharded_search(engine, post, Xc_shard, shard_offset: int, score, mustar=0.0, group=None):
+    """Score this rank's candidate rows on its GPU, then one all-gather for the argmax."""
+    out = engine.predict(post, Xc_shard, score=score, mustar=mustar, want_mu=False, want_var=False,
+                         want_score=False, want_best=True)
+    gidx = out["best_idx"] + shard_offset if out["best_idx"] >= 0 else -1
+    return allgather_argmax(out["best_val"], gidx, device=engine.device, group=group)

@@ -105,6 +105,20 @@ class Engine:
         md.d_G = post.G.data_ptr() if (with_var and post.G is not None) else 0
         return md
 
+    # ---- per-kernel event timing ---------------------------------------------
+    def profile(self, on=True):
+        self.lib.ppbo_profile_enable(self.ctx, int(on))
+        self.lib.ppbo_profile_reset(self.ctx)
+
+    def profile_reset(self):
+        self.lib.ppbo_profile_reset(self.ctx)
+
+    def profile_read(self, name):
+        tot, cnt = C.c_double(0.0), C.c_int(0)
+        rc = self.lib.ppbo_profile_read(self.ctx, name.encode(), C.byref(tot), C.byref(cnt))
+        self._check(rc, "ppbo_profile_read")
+        return tot.value, cnt.value
+
     # ---- K1 / K2 --------------------------------------------------------
     def gram(self, X, theta, kernel="SE_kernel", shrink=SHRINKAGE):
         X = self.dev(X)

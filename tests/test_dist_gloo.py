@@ -1,0 +1,76 @@
+"""CPU, world_size=2, gloo: the sharded-argmax exchange (the only collective on the path)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ppbo_amd.dist import allgather_argmax, combine_best, shard_bounds
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, scores, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_bounds(len(scores), rank, world)
+    loc = scores[lo:hi]
+    if len(loc):
+        li = int(np.argmax(loc))
+        v, gi = float(loc[li]), lo + li
+    else:
+        v, gi = float("nan"), -1
+    out = allgather_argmax(v, gi)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["plain", "tie_across_shards", "ragged"])
+def test_sharded_argmax_two_ranks(case):
+    rng = np.random.default_rng(0)
+    if case == "plain":
+        scores = rng.standard_normal(1000)
+    elif case == "tie_across_shards":
+        scores = rng.standard_normal(1000)
+        scores[10] = scores[900] = 9.0       # equal maxima on both shards -> lowest index wins
+    else:
+        scores = rng.standard_normal(7)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, scores, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, (v, i) in res:
+        assert i == int(np.argmax(scores))
+        assert v == float(scores.max())
+
+
+def test_shard_bounds_cover_everything():
+    for M in (0, 1, 7, 65536, 262144):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(M, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == M
+            assert all(spans[k][1] == spans[k + 1][0] for k in range(w - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_combine_best_semantics():
+    v, i = combine_best(torch.tensor([1.0, 3.0, 3.0, float("nan")]), torch.tensor([5, 9, 2, 1]))
+    assert (v, i) == (3.0, 2)
+    v, i = combine_best(torch.tensor([float("nan")]), torch.tensor([-1]))
+    assert i == -1
