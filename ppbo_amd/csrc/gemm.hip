@@ -7,10 +7,11 @@
 namespace {
 
 using namespace gemm64;
+using GC = Cfg<2, 2, 4, 4>;   // 128 x 128 tile, 4 wavefronts of 64 x 64
+constexpr int BM = GC::BM, BN = GC::BN;
 
 template <int ALAY, int BLAY>
 __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
-  extern __shared__ double lds[];
   if (g.batch > 1) {
     g.A += (size_t)blockIdx.y * g.strideA;
     g.B += (size_t)blockIdx.y * g.strideB;
@@ -31,17 +32,17 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
   if (g.klo_mode == 1) kbeg = (m0 > n0 ? m0 : n0);
   else if (g.klo_mode == 2) kbeg = n0;
   double4_t acc[4][4];
-  zero_acc(acc);
-  mainloop<ALAY, BLAY>(g.A, g.lda, g.B, g.ldb, g.M, g.N, g.K, m0, n0, kbeg, kend, lds, acc);
+  zero_acc<GC>(acc);
+  mainloop<GC, ALAY, BLAY>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0, kbeg, kend, acc);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = m0 + acc_row(i, r);
+      const int row = m0 + acc_row<GC>(i, r);
       if (row >= g.M) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int col = n0 + acc_col(j);
+        const int col = n0 + acc_col<GC>(j);
         if (col >= g.N) continue;
         double* c = g.C + (size_t)row * g.ldc + col;
         double v = g.alpha * acc[i][j][r];
@@ -55,8 +56,8 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
 
 int ppbo_gemm_launch(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return 0;
-  const int ntm = (g.M + gemm64::BM - 1) / gemm64::BM, ntn = (g.N + gemm64::BN - 1) / gemm64::BN;
-  const size_t lds = gemm64::LDS_DOUBLES * sizeof(double);
+  const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+  const size_t lds = GC::LDS_DOUBLES * sizeof(double);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)dgemm_kernel<KC, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

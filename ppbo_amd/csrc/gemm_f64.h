@@ -1,18 +1,21 @@
 // fp64 MFMA tile engine (v_mfma_f64_16x16x4_f64) shared by the dense kernels.
 //
-// One 256-thread workgroup (4 wavefronts, 2x2) owns a 128x128 output tile; each
-// wavefront owns 64x64 = 4x4 MFMA tiles (64 fp64 accumulators per lane).  The
-// K dimension is consumed in chunks of 16 through double-buffered LDS with
-// register-staged prefetch (global loads of chunk k+1 are in flight while the
-// MFMAs of chunk k issue).
+// A workgroup of WM x WN wavefronts owns a BM x BN output tile (BM = WM*TM*16,
+// BN = WN*TN*16); each wavefront owns TM x TN MFMA tiles (4 fp64 accumulators per lane
+// and tile).  The K dimension is consumed in chunks of 16 through double-buffered LDS
+// with register-staged prefetch (global loads of chunk k+1 are in flight while the MFMAs
+// of chunk k issue).  Measured on MI355X (tools/mfma_f64_bench.hip): one wavefront alone
+// issues an fp64 MFMA only every ~138 cycles; the 64-cycle pipe fills only with several
+// wavefronts per SIMD, so small per-wave tiles (few accumulator VGPRs, 4+ waves/SIMD)
+// beat large ones.
 //
 // Operand storage in HBM is described per operand:
 //   KC  "k contiguous"  : element (r, k) at base[r*ld + k]   (row-major [rows][K])
 //   RC  "row contiguous": element (r, k) at base[k*ld + r]   (row-major [K][rows])
 // LDS images keep the source orientation and are padded so that the MFMA
 // fragment read (lane l -> row l&15, k l>>4) is bank-conflict free:
-//   KC image [128][16+2]  : dword bank = (36 r + 2 k) mod 64  -> 64 distinct banks / 32 lanes
-//   RC image [16][128+16] : row stride 288 dwords = 32 mod 64 -> two k rows use disjoint halves
+//   KC image [rows][16+2]  : dword bank = (36 r + 2 k) mod 64  -> 64 distinct banks / 32 lanes
+//   RC image [16][rows+16] : row stride = 32 dwords mod 64 -> two k rows use disjoint halves
 // f64 MFMA fragment maps (cdna_hip_programming.md s3): A[l&15][l>>4], B[l>>4][l&15],
 // C/D: col = l&15, row = (l>>4) + 4*reg.
 #pragma once
@@ -20,149 +23,196 @@
 
 namespace gemm64 {
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int KC_LD = BK + 2;     // 18
-constexpr int RC_LD = BM + 16;    // 144
-constexpr int IMG = BM * KC_LD;   // 2304 doubles == BK * RC_LD
-static_assert(BM * KC_LD == BK * RC_LD, "both images have the same footprint");
-constexpr int LDS_DOUBLES = 4 * IMG;  // A,B x 2 buffers = 73,728 bytes
+constexpr int BK = 16;
+constexpr int KC_LD = BK + 2;  // 18
 
 enum Layout { KC = 0, RC = 1 };
 
-struct Stage {  // 8 doubles of one operand tile per thread
-  double2 v[4];
+template <int WM_, int WN_, int TM_, int TN_>
+struct Cfg {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+  static constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  static constexpr int NT = 64 * WM * WN;
+  static constexpr int IMG_A = BM * KC_LD;   // == BK * (BM + 16)
+  static constexpr int IMG_B = BN * KC_LD;
+  static constexpr int LDS_DOUBLES = 2 * (IMG_A + IMG_B);
+  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile must split evenly over the threads");
 };
 
-// Load this thread's share of a [128 rows x 16 k] operand tile into registers.
-template <int LAY>
-__device__ __forceinline__ void load_tile(const double* __restrict__ base, int ld, int r0, int k0, int rows,
-                                          int K, bool fast, Stage& st) {
+// All LDS traffic goes through this symbol with integer offsets so the compiler keeps the
+// accesses in the LDS address space (ds_read_b64 / ds_write_b128).  Routing the image
+// pointers through a runtime-indexed pointer array made hipcc fall back to flat_load with a
+// combined vmcnt(0)/lgkmcnt(0) wait in front of every MFMA group (-45 % throughput).
+extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+
+// thread -> (row, k) of its p-th double2 inside a [ROWS x 16] operand tile
+template <int LAY, int ROWS, int NT>
+__device__ __forceinline__ void tile_coord(int p, int& r, int& k) {
   const int t = threadIdx.x;
+  if (LAY == KC) { r = p * (NT / 8) + (t >> 3); k = (t & 7) * 2; }
+  else { constexpr int TPR = ROWS / 2; k = p * (NT / TPR) + t / TPR; r = (t % TPR) * 2; }
+}
+
+template <int LAY, int ROWS, int NT, bool FAST>
+__device__ __forceinline__ double2 load_elem(const double* __restrict__ base, int ld, int r0, int k0, int rows,
+                                             int K, int p) {
+  int r, k;
+  tile_coord<LAY, ROWS, NT>(p, r, k);
+  const double* src = (LAY == KC) ? base + (size_t)(r0 + r) * ld + (k0 + k) : base + (size_t)(k0 + k) * ld + (r0 + r);
+  if (FAST) return *reinterpret_cast<const double2*>(src);
+  double2 v;
   if (LAY == KC) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int r = p * 32 + (t >> 3), k = (t & 7) * 2;
-      const double* src = base + (size_t)(r0 + r) * ld + (k0 + k);
-      if (fast) {
-        st.v[p] = *reinterpret_cast<const double2*>(src);
-      } else {
-        const bool rok = (r0 + r) < rows;
-        st.v[p].x = (rok && (k0 + k) < K) ? src[0] : 0.0;
-        st.v[p].y = (rok && (k0 + k + 1) < K) ? src[1] : 0.0;
-      }
-    }
+    const bool rok = (r0 + r) < rows;
+    v.x = (rok && (k0 + k) < K) ? src[0] : 0.0;
+    v.y = (rok && (k0 + k + 1) < K) ? src[1] : 0.0;
   } else {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int k = p * 4 + (t >> 6), r = (t & 63) * 2;
-      const double* src = base + (size_t)(k0 + k) * ld + (r0 + r);
-      if (fast) {
-        st.v[p] = *reinterpret_cast<const double2*>(src);
-      } else {
-        const bool kok = (k0 + k) < K;
-        st.v[p].x = (kok && (r0 + r) < rows) ? src[0] : 0.0;
-        st.v[p].y = (kok && (r0 + r + 1) < rows) ? src[1] : 0.0;
-      }
-    }
+    const bool kok = (k0 + k) < K;
+    v.x = (kok && (r0 + r) < rows) ? src[0] : 0.0;
+    v.y = (kok && (r0 + r + 1) < rows) ? src[1] : 0.0;
   }
+  return v;
 }
 
-template <int LAY>
-__device__ __forceinline__ void store_tile(double* __restrict__ img, const Stage& st) {
-  const int t = threadIdx.x;
-  if (LAY == KC) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int r = p * 32 + (t >> 3), k = (t & 7) * 2;
-      *reinterpret_cast<double2*>(img + r * KC_LD + k) = st.v[p];
-    }
-  } else {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int k = p * 4 + (t >> 6), r = (t & 63) * 2;
-      *reinterpret_cast<double2*>(img + k * RC_LD + r) = st.v[p];
-    }
-  }
+template <int LAY, int ROWS, int NT>
+__device__ __forceinline__ void store_elem(int img, int p, double2 v) {
+  int r, k;
+  tile_coord<LAY, ROWS, NT>(p, r, k);
+  const int off = (LAY == KC) ? r * KC_LD + k : k * (ROWS + 16) + r;
+  *reinterpret_cast<double2*>(&lds_dyn[img + off]) = v;
 }
 
-template <int LAY>
-__device__ __forceinline__ double frag(const double* __restrict__ img, int r, int k) {
-  return (LAY == KC) ? img[r * KC_LD + k] : img[k * RC_LD + r];
-}
-
-template <int LAY>
-__device__ __forceinline__ bool tile_fast(const double* base, int ld, int r0, int k0, int rows, int K) {
-  const bool inb = (r0 + BM <= rows) && (k0 + BK <= K);
+// whole K range [kbeg, kend) of this operand tile is in bounds and 16-byte aligned
+template <int ROWS>
+__device__ __forceinline__ bool tile_fast(const double* base, int ld, int r0, int kbeg, int kend, int rows) {
+  const bool inb = (r0 + ROWS <= rows) && (((kend - kbeg) % BK) == 0);
   const bool al = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0) && ((r0 & 1) == 0) &&
-                  ((k0 & 1) == 0);
+                  ((kbeg & 1) == 0);
   return inb && al;
 }
 
-// acc[ti][tj] += A[m0.., kbeg..kend) * B[kbeg..kend), n0..]
-template <int ALAY, int BLAY>
-__device__ __forceinline__ void mainloop(const double* __restrict__ A, int lda, const double* __restrict__ B,
-                                         int ldb, int M, int N, int K, int m0, int n0, int kbeg, int kend,
-                                         double* __restrict__ lds, double4_t acc[4][4]) {
-  double* Aimg[2] = {lds, lds + 2 * IMG};
-  double* Bimg[2] = {lds + IMG, lds + 3 * IMG};
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lr = lane & 15, lk = lane >> 4;
+// per-lane LDS offset (doubles) of fragment element (row r, k) relative to the image start
+template <int LAY, int ROWS>
+__device__ __forceinline__ int frag_off(int r, int k) {
+  return (LAY == KC) ? r * KC_LD + k : k * (ROWS + 16) + r;
+}
 
+template <class C, int ALAY, int BLAY, bool FAST>
+__device__ __forceinline__ void mainloop_impl(const double* __restrict__ A, int lda, const double* __restrict__ B,
+                                              int ldb, int M, int N, int m0, int n0, int kbeg, int kend,
+                                              double4_t acc[C::TM][C::TN]) {
+  constexpr int BUF = C::IMG_A + C::IMG_B;   // buffer b: A image at b*BUF, B image at b*BUF + IMG_A
+  constexpr int PA = C::BM * 8 / C::NT, PB = C::BN * 8 / C::NT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int lr = lane & 15, lk = lane >> 4;
   const int nk = (kend - kbeg + BK - 1) / BK;
-  if (nk <= 0) return;
-  Stage sa, sb;
-  load_tile<ALAY>(A, lda, m0, kbeg, M, kend, tile_fast<ALAY>(A, lda, m0, kbeg, M, kend), sa);
-  load_tile<BLAY>(B, ldb, n0, kbeg, N, kend, tile_fast<BLAY>(B, ldb, n0, kbeg, N, kend), sb);
-  store_tile<ALAY>(Aimg[0], sa);
-  store_tile<BLAY>(Bimg[0], sb);
+  // lane-constant LDS offsets; everything else in the loop is an immediate
+  const int a_lane = frag_off<ALAY, C::BM>(wm * C::TM * 16 + lr, lk);
+  const int b_lane = C::IMG_A + frag_off<BLAY, C::BN>(wn * C::TN * 16 + lr, lk);
+  constexpr int A_I = (ALAY == KC) ? 16 * KC_LD : 16;              // next 16-row tile
+  constexpr int B_J = (BLAY == KC) ? 16 * KC_LD : 16;
+  constexpr int A_K = (ALAY == KC) ? 4 : 4 * (C::BM + 16);         // next k-step of 4
+  constexpr int B_K = (BLAY == KC) ? 4 : 4 * (C::BN + 16);
+  // register staging (plain arrays, fully unrolled: they must stay in VGPRs)
+  double2 ra[PA], rb[PB];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) ra[p] = load_elem<ALAY, C::BM, C::NT, FAST>(A, lda, m0, kbeg, M, kend, p);
+#pragma unroll
+  for (int p = 0; p < PB; ++p) rb[p] = load_elem<BLAY, C::BN, C::NT, FAST>(B, ldb, n0, kbeg, N, kend, p);
+#pragma unroll
+  for (int p = 0; p < PA; ++p) store_elem<ALAY, C::BM, C::NT>(0, p, ra[p]);
+#pragma unroll
+  for (int p = 0; p < PB; ++p) store_elem<BLAY, C::BN, C::NT>(C::IMG_A, p, rb[p]);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = (kt + 1) < nk;
-    if (more) {
-      const int k0 = kbeg + (kt + 1) * BK;
-      load_tile<ALAY>(A, lda, m0, k0, M, kend, tile_fast<ALAY>(A, lda, m0, k0, M, kend), sa);
-      load_tile<BLAY>(B, ldb, n0, k0, N, kend, tile_fast<BLAY>(B, ldb, n0, k0, N, kend), sb);
-    }
-    const double* ai = Aimg[cur];
-    const double* bi = Bimg[cur];
+    const int cur = (kt & 1) * BUF;
+    // Prefetch chunk kt+1 (the last iteration re-reads its own chunk: harmless, keeps the
+    // loop body branch-free so the staging registers are never demoted to scratch).
+    const int k0 = kbeg + ((kt + 1 < nk) ? (kt + 1) : kt) * BK;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      double a[4], b[4];
+    for (int p = 0; p < PA; ++p) ra[p] = load_elem<ALAY, C::BM, C::NT, FAST>(A, lda, m0, k0, M, kend, p);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = frag<ALAY>(ai, wm * 64 + i * 16 + lr, kk * 4 + lk);
+    for (int p = 0; p < PB; ++p) rb[p] = load_elem<BLAY, C::BN, C::NT, FAST>(B, ldb, n0, k0, N, kend, p);
+    // register double-buffered fragments: the LDS reads of k-step kk+1 are in flight while
+    // the MFMAs of k-step kk issue
+    const double* la = lds_dyn + cur + a_lane;
+    const double* lb = lds_dyn + cur + b_lane;
+    double a0[C::TM], b0[C::TN], a1[C::TM], b1[C::TN];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = frag<BLAY>(bi, wn * 64 + j * 16 + lr, kk * 4 + lk);
+    for (int i = 0; i < C::TM; ++i) a0[i] = la[i * A_I];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < C::TN; ++j) b0[j] = lb[j * B_J];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      store_tile<ALAY>(Aimg[cur ^ 1], sa);
-      store_tile<BLAY>(Bimg[cur ^ 1], sb);
-    }
+    for (int i = 0; i < C::TM; ++i) a1[i] = la[A_K + i * A_I];
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) b1[j] = lb[B_K + j * B_J];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) a0[i] = la[2 * A_K + i * A_I];
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) b0[j] = lb[2 * B_K + j * B_J];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) a1[i] = la[3 * A_K + i * A_I];
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) b1[j] = lb[3 * B_K + j * B_J];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    // the other buffer was last read in iteration kt-1 (barrier since then): safe to overwrite
+#pragma unroll
+    for (int p = 0; p < PA; ++p) store_elem<ALAY, C::BM, C::NT>(BUF - cur, p, ra[p]);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) store_elem<BLAY, C::BN, C::NT>(BUF - cur + C::IMG_A, p, rb[p]);
     __syncthreads();
   }
 }
 
-__device__ __forceinline__ void zero_acc(double4_t acc[4][4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+// ALWAYS_FAST: the host has verified that every tile of the launch is in bounds and aligned,
+// so the guarded (scalar, zero-filling) loop is not even compiled into the kernel.
+template <class C, int ALAY, int BLAY, bool ALWAYS_FAST = false>
+__device__ __forceinline__ void mainloop(const double* __restrict__ A, int lda, const double* __restrict__ B,
+                                         int ldb, int M, int N, int m0, int n0, int kbeg, int kend,
+                                         double4_t acc[C::TM][C::TN]) {
+  if (kend <= kbeg) return;
+  if (ALWAYS_FAST) {
+    mainloop_impl<C, ALAY, BLAY, true>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc);
+    return;
+  }
+  const bool fast = tile_fast<C::BM>(A, lda, m0, kbeg, kend, M) && tile_fast<C::BN>(B, ldb, n0, kbeg, kend, N);
+  if (fast) mainloop_impl<C, ALAY, BLAY, true>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc);
+  else mainloop_impl<C, ALAY, BLAY, false>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc);
 }
 
-// element (row, col) of accumulator acc[i][j][r] inside the 128x128 tile
+template <class C>
+__device__ __forceinline__ void zero_acc(double4_t acc[C::TM][C::TN]) {
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+}
+
+// element (row, col) of accumulator acc[i][j][r] inside the BM x BN tile
+template <class C>
 __device__ __forceinline__ int acc_row(int i, int r) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  return (wave >> 1) * 64 + i * 16 + (lane >> 4) + 4 * r;
+  return ((wave / C::WN) * C::TM + i) * 16 + (lane >> 4) + 4 * r;
 }
+template <class C>
 __device__ __forceinline__ int acc_col(int j) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  return (wave & 1) * 64 + j * 16 + (lane & 15);
+  return ((wave % C::WN) * C::TN + j) * 16 + (lane & 15);
 }
 
 }  // namespace gemm64

@@ -113,12 +113,12 @@ __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
   }
 }
 
-// Y = G K* ; slab[mt][c] = sum over the 128 rows of tile mt of Y[i,c]^2
-__global__ __launch_bounds__(256, 2) void quadform_kernel(const double* __restrict__ G, int N,
-                                                          const double* __restrict__ Kt, int ldk, int M,
-                                                          int tri_block, double* __restrict__ slab, int ntm,
-                                                          int ntn, int swizzle) {
-  extern __shared__ double lds[];
+// Y = G K* ; slab[mt][c] = sum over the BM rows of tile mt of Y[i,c]^2
+template <class C, int MINW, bool ALWAYS_FAST>
+__global__ __launch_bounds__(C::NT, MINW) void quadform_kernel(const double* __restrict__ G, int N,
+                                                               const double* __restrict__ Kt, int ldk, int M,
+                                                               int tri_block, double* __restrict__ slab, int ntm,
+                                                               int ntn, int swizzle) {
   int id = blockIdx.x;
   if (swizzle) {                       // XCD-aware: consecutive logical ids share an XCD / L2
     const int per = gridDim.x >> 3;
@@ -126,30 +126,85 @@ __global__ __launch_bounds__(256, 2) void quadform_kernel(const double* __restri
   }
   // row tile fastest, heaviest (largest K range) first
   const int mt = ntm - 1 - (id % ntm), nt = id / ntm;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int e = ((m0 + BM + tri_block - 1) / tri_block) * tri_block;
+  const int m0 = mt * C::BM, n0 = nt * C::BN;
+  const int e = ((m0 + C::BM + tri_block - 1) / tri_block) * tri_block;
   const int kend = e < N ? e : N;
-  double4_t acc[4][4];
-  zero_acc(acc);
-  mainloop<KC, RC>(G, N, Kt, ldk, N, M, N, m0, n0, 0, kend, lds, acc);
+  double4_t acc[C::TM][C::TN];
+  zero_acc<C>(acc);
+  mainloop<C, KC, RC, ALWAYS_FAST>(G, N, Kt, ldk, N, M, m0, n0, 0, kend, acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  double* red = lds;  // [2][128]; mainloop ended with a barrier
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  double* red = lds_dyn;  // [WM][BN]; mainloop ended with a barrier
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < C::TN; ++j) {
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < C::TM; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
-    if (lane < 16) red[wm * BN + wn * 64 + j * 16 + lane] = s;
+    if (lane < 16) red[wm * C::BN + (wn * C::TN + j) * 16 + lane] = s;
   }
   __syncthreads();
-  if (threadIdx.x < BN) {
+  if (threadIdx.x < C::BN) {
     const int c = n0 + threadIdx.x;
-    if (c < M) slab[(size_t)mt * M + c] = red[threadIdx.x] + red[BN + threadIdx.x];
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < C::WM; ++w) t += red[w * C::BN + threadIdx.x];
+    if (c < M) slab[(size_t)mt * M + c] = t;
+  }
+}
+
+// tile shapes tried on MI355X: variant id -> (WM, WN, TM, TN, min waves/SIMD)
+using QF0 = Cfg<2, 2, 4, 4>;   // 4 waves of 64x64, 2 WG/CU -> 2 waves/SIMD
+using QF1 = Cfg<2, 4, 4, 2>;   // 8 waves of 64x32, 2 WG/CU -> 4 waves/SIMD
+using QF2 = Cfg<4, 2, 2, 4>;   // 8 waves of 32x64
+using QF3 = Cfg<4, 4, 2, 2>;   // 16 waves of 32x32, 1 WG/CU -> 4 waves/SIMD
+using QF4 = Cfg<4, 4, 2, 2>;   // same tile, 2 WG/CU -> 8 waves/SIMD (<= 64 VGPRs)
+
+template <class C, int MINW>
+int launch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, int ldk, int Mc, int mblk,
+                    double* slab, hipStream_t s) {
+  const size_t lds = C::LDS_DOUBLES * sizeof(double);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)quadform_kernel<C, MINW, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)quadform_kernel<C, MINW, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const int ntm = (N + C::BM - 1) / C::BM, ntn = (Mc + C::BN - 1) / C::BN;
+  const int grid = ntm * ntn;
+  const int swz = (grid % 8 == 0 && grid >= 64) ? 1 : 0;
+  // every tile in bounds, 16-byte aligned, and every K range a multiple of 16?
+  const bool fast = (N % C::BM == 0) && (Mc % C::BN == 0) && (N % 2 == 0) && (ldk % 2 == 0) && (mblk % 16 == 0 || mblk == 1 || (C::BM % mblk == 0)) &&
+                    ((reinterpret_cast<uintptr_t>(G) & 15) == 0) && ((reinterpret_cast<uintptr_t>(Kt) & 15) == 0);
+  if (fast) quadform_kernel<C, MINW, true><<<grid, C::NT, lds, s>>>(G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn, swz);
+  else quadform_kernel<C, MINW, false><<<grid, C::NT, lds, s>>>(G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn, swz);
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int quadform_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PPBO_QF_VARIANT");
+    v = e ? atoi(e) : 2;   // measured best on MI355X: 8 waves of 32x64, 4 waves/SIMD
+    if (v < 0 || v > 4) v = 0;
+  }
+  return v;
+}
+
+int dispatch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, int ldk, int Mc, int mblk,
+                      double* slab, hipStream_t s) {
+  switch (quadform_variant()) {
+    case 1: return launch_quadform<QF1, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
+    case 2: return launch_quadform<QF2, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
+    case 3: return launch_quadform<QF3, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
+    case 4: return launch_quadform<QF4, 8>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
+    default: return launch_quadform<QF0, 2>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
   }
 }
 
@@ -327,7 +382,7 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
   const int N = model->N, mblk = model->m + 1, n_q = N / mblk;
   const int64_t chunk_cap = 65536;
   const int64_t n_chunks = (M + chunk_cap - 1) / chunk_cap;
-  const int ntm = (N + BM - 1) / BM;
+  const int ntm = (N + 127) / 128;   // every quadform variant uses 128-row tiles
 
   // workspaces sized for the largest chunk
   const int Mc_max = (int)(M < chunk_cap ? M : chunk_cap);
@@ -348,12 +403,6 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
   if (!bests) return (int)hipErrorOutOfMemory;
   Best* chunk_best = bests + sblocks_max;
 
-  const size_t qf_lds = LDS_DOUBLES * sizeof(double);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)quadform_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qf_lds);
-    attr_done = true;
-  }
 
   for (int64_t ch = 0; ch < n_chunks; ++ch) {
     const int64_t c_beg = ch * chunk_cap;
@@ -368,12 +417,8 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
     }
     PPBO_LAUNCH_CHECK(ctx);
     if (want_var) {
-      const int ntn = (Mc + BN - 1) / BN;
-      const int grid = ntm * ntn;
       PpboProfScope pf(ctx, ppbo_ctx::PF_QUADFORM, s);
-      quadform_kernel<<<grid, 256, qf_lds, s>>>(model->d_G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn,
-                                                (grid % 8 == 0 && grid >= 64) ? 1 : 0);
-      PPBO_LAUNCH_CHECK(ctx);
+      if (int rc = dispatch_quadform(ctx, model->d_G, N, Kt, ldk, Mc, mblk, slab, s)) return rc;
     }
     const int sblocks = (Mc + 255) / 256;
     PpboProfScope pfs(ctx, ppbo_ctx::PF_SCORE, s);
