@@ -185,6 +185,12 @@ int ppbo_dgemm(ppbo_ctx* ctx, int transA, int transB, int M, int N, int K, doubl
                const double* d_A, int lda, const double* d_B, int ldb, double beta,
                double* d_C, int ldc, void* stream);
 
+/* y = op(A) x for a square fp64 matrix; lower != 0 reads only the lower triangle (A is then
+ * treated as lower-triangular).  Used for alpha = Sigma^-1 f_MAP (src/gp_model.py:445) and
+ * prior draws L z (src/gp_model.py:374). */
+int ppbo_dgemv(ppbo_ctx* ctx, int trans, int lower, int N, const double* d_A, int lda,
+               const double* d_x, double* d_y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -290,6 +290,13 @@ int ppbo_potrf(ppbo_ctx* ctx, double* d_A, int N, int lda, int* h_info, void* st
   return 0;
 }
 
+int ppbo_dgemv(ppbo_ctx* ctx, int trans, int lower, int N, const double* d_A, int lda, const double* d_x,
+               double* d_y, void* stream) {
+  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_REQUIRE(ctx, d_A && d_x && d_y && N > 0 && lda >= N, "arguments");
+  return ppbo_gemv_async(ctx, d_A, N, lda, d_x, d_y, trans, lower, (hipStream_t)stream);
+}
+
 int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int* h_info, void* stream) {
   PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
   PPBO_REQUIRE(ctx, d_A && d_Ainv && N > 0, "matrix");

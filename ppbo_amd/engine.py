@@ -168,6 +168,15 @@ class Engine:
         self._check(rc, "ppbo_dgemm")
         return Cc
 
+    def dgemv(self, A, x, trans=False, lower=False):
+        A, x = self.dev(A), self.dev(x).reshape(-1)
+        N = A.shape[0]
+        y = self.empty(N)
+        rc = self.lib.ppbo_dgemv(self.ctx, int(trans), int(lower), N, _ptr(A), A.stride(0), _ptr(x), _ptr(y),
+                                 self._stream())
+        self._check(rc, "ppbo_dgemv")
+        return y
+
     # ---- K5 / fit -------------------------------------------------------------
     def laplace_terms(self, f, m, sigma):
         f = self.dev(f).reshape(-1)

@@ -1,0 +1,382 @@
+"""Drop-in GPModel: the reference's object surface (src/gp_model.py) on top of libppbo_hip.so.
+
+Same constructor, methods, argument meaning and print-and-continue error behaviour as the
+reference class; every O(N^2)/O(N^3)/O(M N^2) operation is a HIP kernel behind the C-ABI:
+  update_Sigma       -> ppbo_gram            (gp_model.py:157-158, kernels.py, misc.py:71-88)
+  update_Sigma_inv   -> ppbo_pd_inverse      (gp_model.py:161-162, misc.py:96-100)
+  update_fMAP        -> ppbo_fit_fmap        (gp_model.py:354-389)
+  Lambda / posterior -> ppbo_posterior       (gp_model.py:111-117, 249-274)
+  mu_pred / mu_Sigma_pred -> ppbo_predict / ppbo_predict_cov   (gp_model.py:441-461)
+  mu_star            -> batched candidate search with on-device argmax (replaces the sequential
+                        differential evolution of gp_model.py:415-437), then a bounded polish.
+Large matrices live on the GPU; the NumPy attributes other code reads (Sigma, Sigma_inv,
+Lambda_MAP, posterior_covariance, ...) are materialised lazily on first access.
+There is no CPU fallback: without the HIP library / a GPU the constructor raises.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import scipy.optimize
+
+from . import kernels as _kernels
+from .engine import NotPositiveDefinite, SCORE_MEAN, get_engine
+from .feedback_processing import FeedbackProcessing
+
+SEARCH_CANDIDATES = 65536      # uniform candidates per mu_star trial
+ZOOM_CANDIDATES = 8192         # candidates per local zoom stage
+ZOOM_RADII = (0.15, 0.05, 0.015, 0.005)
+
+
+class GPModel:
+    def __init__(self, PPBO_settings, engine=None):
+        self.COVARIANCE_SHRINKAGE = 1e-6            # gp_model.py:26
+        self.eng = engine if engine is not None else get_engine()
+        s = PPBO_settings
+        self.verbose = s.verbose
+        self.FP = None
+        self.D = s.D
+        self.original_bounds = s.original_bounds
+        self.bounds = ((0, 1),) * self.D
+        self.X = None
+        self.N = None
+        self.m = s.n_pseudoobservations
+        self.obs_indices = self.pseudobs_indices = self.latest_obs_indices = None
+        self.alpha_grid_distribution = s.alpha_grid_distribution
+        self.TGN_speed = s.TGN_speed
+        self.n_gausshermite_sample_points = s.n_gausshermite_sample_points
+        self.xi_acquisition_function = s.xi_acquisition_function
+        self.kernel = _kernels.BY_NAME[s.kernel]    # the reference eval()s the string (gp_model.py:48)
+        self.theta_initial = s.theta_initial
+        self.theta = None
+        self.fMAP = None
+        self.fMAP_finding_trials = 1
+        self.fMAP_optimizer = s.fMAP_optimizer
+        self.fMAP_random_initial_vector = True
+        self.mustar_finding_trials = s.mustar_finding_trials
+        self.mustar_previous_iteration = 0
+        self.mustar = None
+        self.xstar = None
+        self.xstars_local = None
+        self.initialization_running = True
+        self.last_iteration = False
+        self.skip_computations_during_initialization = s.skip_computations_during_initialization
+        self.skip_xstaroptimization_during_initialization = s.skip_xstaroptimization_during_initialization
+        self.fit_stats = None
+        # device state
+        self._dX = self._dSigma = self._dSigma_inv = None
+        self._post = None           # engine.Posterior with G (variance operator)
+        self._post_mean = None      # Posterior usable for the mean only (alpha current, no G)
+        self._host = {}
+
+    # ------------------------------------------------------------------ data
+    def update_feedback_processing_object(self, X_obs):
+        if self.FP is None:
+            self.FP = FeedbackProcessing(self.D, self.m, self.original_bounds, self.alpha_grid_distribution,
+                                         self.TGN_speed)
+            self.FP.initialize_data(X_obs)
+        else:
+            self.FP.update_data(X_obs)
+
+    def update_data(self):
+        self.X = self.FP.X
+        self.N = self.FP.N
+        self.obs_indices = self.FP.obs_indices
+        self.pseudobs_indices = self.FP.pseudobs_indices
+        self.latest_obs_indices = self.FP.latest_obs_indices
+        self._dX = self.eng.dev(self.X)
+
+    def turn_initialization_off(self):
+        self.initialization_running = False
+        self.FP.alpha_grid_distribution = self.alpha_grid_distribution
+
+    def set_last_iteration(self):
+        self.last_iteration = True
+
+    def is_pseudobs(self, i):
+        return self.FP.is_pseudobs(i)
+
+    # ------------------------------------------------------------------ lazily downloaded matrices
+    def _lazy(self, key, make):
+        if key not in self._host:
+            self._host[key] = make()
+        return self._host[key]
+
+    def _invalidate(self, *keys):
+        for k in keys:
+            self._host.pop(k, None)
+
+    @property
+    def Sigma(self):
+        return None if self._dSigma is None else self._lazy("Sigma", lambda: self._dSigma.cpu().numpy())
+
+    @property
+    def Sigma_inv(self):
+        return None if self._dSigma_inv is None else self._lazy("Sigma_inv", lambda: self._dSigma_inv.cpu().numpy())
+
+    @property
+    def Lambda_MAP(self):
+        if self._post is None:
+            return None
+        return self._lazy("Lambda_MAP", lambda: self._dense_lambda(self._post.lam_diag.cpu().numpy(),
+                                                                   self._post.lam_off.cpu().numpy()))
+
+    @property
+    def posterior_covariance(self):
+        if self._post is None:
+            return None
+        if self._post.P is None:     # computed on demand: P = R^T R (one MFMA GEMM)
+            self._post = self.eng.posterior(self._dX, self.theta, self.kernel.__name__, self._dSigma_inv,
+                                            self.eng.dev(self.fMAP), self.m, want_P=True)
+        return self._lazy("P", lambda: self._post.P.cpu().numpy())
+
+    @property
+    def posterior_covariance_inv(self):
+        if self._post is None:
+            return None
+        return self._lazy("Pinv", lambda: self.Sigma_inv - self.Lambda_MAP)
+
+    def _dense_lambda(self, diag, off):
+        N, mb = self.N, self.m + 1
+        L = np.diag(diag)
+        idx = np.arange(N)
+        pse = idx[idx % mb != 0]
+        obs = (pse // mb) * mb
+        L[obs, pse] = off[pse]
+        L[pse, obs] = off[pse]
+        return L
+
+    # ------------------------------------------------------------------ covariance
+    def create_Gramian(self, X1, X2, kernel, *args):
+        theta = args[0]
+        return self.eng.gram(np.asarray(X1), theta, kernel.__name__, self.COVARIANCE_SHRINKAGE).cpu().numpy()
+
+    def create_Gramian_nonsquare(self, X1, X2, kernel, *args):
+        return kernel(X1, X2, *args)
+
+    def update_Sigma(self, theta):
+        self._dSigma = self.eng.gram(self._dX, theta, self.kernel.__name__, self.COVARIANCE_SHRINKAGE)
+        self._invalidate("Sigma")
+
+    def update_Sigma_inv(self, theta):
+        self._dSigma_inv = self.eng.pd_inverse(self._dSigma)
+        self._invalidate("Sigma_inv", "Pinv")
+
+    def set_theta(self):
+        self.theta = self.theta_initial
+        if self.theta[1] is None:
+            self.theta[1] = 1
+        if self.theta[2] is None:
+            self.theta[2] = 0.1
+        if self.theta[0] is None:
+            self.theta[0] = 8
+
+    # ------------------------------------------------------------------ functional T
+    def _sinv_dev(self, Sigma_inv_):
+        return self._dSigma_inv if Sigma_inv_ is None else self.eng.dev(Sigma_inv_)
+
+    def T(self, f, theta, Sigma_inv_=None):
+        T, _ = self.eng.T_and_grad(self._sinv_dev(Sigma_inv_), np.asarray(f, dtype=float).ravel(), self.m, theta[0])
+        return T
+
+    def T_grad(self, f, theta, Sigma_inv_=None):
+        _, g = self.eng.T_and_grad(self._sinv_dev(Sigma_inv_), np.asarray(f, dtype=float).ravel(), self.m, theta[0])
+        return g.cpu().numpy()
+
+    def create_Lambda(self, f, sigma):
+        _, _, ld, lo = self.eng.laplace_terms(np.asarray(f, dtype=float).ravel(), self.m, sigma)
+        return self._dense_lambda(ld.cpu().numpy(), lo.cpu().numpy())
+
+    def T_hessian(self, f, theta, Sigma_inv_=None):
+        Sinv = self.Sigma_inv if Sigma_inv_ is None else np.asarray(Sigma_inv_)
+        return -Sinv + self.create_Lambda(f, theta[0])
+
+    def sum_Phi_vec(self, order_of_derivative, f, sigma, over_all_indices=False):
+        """Per-query sums of gp_model.py:206-218 recovered from the device Laplace terms."""
+        f = np.asarray(f, dtype=float).ravel()
+        mb = self.m + 1
+        delta = (f.reshape(-1, mb)[:, 1:] - f.reshape(-1, mb)[:, :1]) / sigma
+        _, beta, ld, _ = self.eng.laplace_terms(f, self.m, sigma)
+        if order_of_derivative == 1:
+            out = beta.cpu().numpy()[::mb] * (sigma * self.m)
+        elif order_of_derivative == 2:
+            out = -ld.cpu().numpy()[::mb] * (self.m * sigma ** 2)
+        else:
+            from scipy.special import ndtr
+            out = ndtr(delta / np.sqrt(2.0)).sum(axis=1)
+        return np.repeat(out, mb) if over_all_indices else out
+
+    # ------------------------------------------------------------------ evidence / hyper-parameters
+    def evidence(self, theta, f_initial):
+        raise NotImplementedError(
+            "evidence() (gp_model.py:278-319) needs a signed log-determinant of the indefinite matrix "
+            "I + Sigma*Lambda; the device library only factors SPD matrices so far (DESIGN.md, next rows). "
+            "There is deliberately no CPU fallback.")
+
+    def optimize_theta(self):
+        raise NotImplementedError("optimize_theta() (gp_model.py:391-413) builds on evidence(); not on the device yet")
+
+    # ------------------------------------------------------------------ f_MAP
+    def _draw_prior(self):
+        """f ~ N(0, Sigma) for the random start (gp_model.py:374,381): L z with the device Cholesky
+        factor and z from the global NumPy stream (the reference uses np.random.multivariate_normal)."""
+        L = self.eng.potrf_(self._dSigma.clone())
+        return self.eng.dgemv(L, np.random.standard_normal(self.N), lower=True)
+
+    def update_fMAP(self, random_initial_vector=None, fmap_finding_trials=None, approx_optimization=False):
+        trials = self.fMAP_finding_trials if fmap_finding_trials is None else fmap_finding_trials
+        rnd = self.fMAP_random_initial_vector if random_initial_vector is None else random_initial_vector
+        gtol = 100.0 if approx_optimization else 1e-4          # gp_model.py:365-368 (SciPy default gtol)
+        if self.verbose:
+            print("MAP-estimation begins...")
+        start = time.time()
+        best_T, best = -np.inf, None
+        for _ in range(trials):
+            if self.fMAP is None or rnd or len(self.fMAP) > self.N:
+                f0 = self._draw_prior()
+            elif len(self.fMAP) < self.N:                        # pad with the mean (gp_model.py:375-377)
+                f0 = np.concatenate([self.fMAP, np.full(self.N - len(self.fMAP), np.mean(self.fMAP))])
+            else:
+                f0 = self.fMAP
+            fm, st = self.eng.fit_fmap(self._dSigma_inv, f0, self.m, self.theta[0], gtol=gtol)
+            if self.verbose:
+                print("... this took " + str(time.time() - start) + " seconds.")
+            if st["T"] > best_T:
+                best_T, best, self.fit_stats = st["T"], fm, st
+        self.fMAP = best.cpu().numpy()
+        self._post = None
+        self._refresh_mean_state(best)
+        self._invalidate("Lambda_MAP", "P", "Pinv")
+
+    def _refresh_mean_state(self, fmap_dev):
+        from .engine import Posterior
+        alpha = self.eng.dgemv(self._dSigma_inv, fmap_dev)
+        self._post_mean = Posterior(self.kernel.__name__, tuple(float(t) for t in self.theta), self.m, self._dX, alpha,
+                                    None, None, None)
+
+    # ------------------------------------------------------------------ orchestration (gp_model.py:87-132)
+    def update_model(self, optimize_theta=False):
+        if self.theta is None:
+            self.set_theta()
+        self.update_Sigma(self.theta)
+        self.update_Sigma_inv(self.theta)
+        init_skip = self.initialization_running and self.skip_computations_during_initialization
+        if init_skip:
+            self.FP.alpha_grid_distribution = "equispaced"
+            self.update_fMAP(random_initial_vector=False, fmap_finding_trials=1, approx_optimization=True)
+        elif self.last_iteration:
+            self.update_fMAP(random_initial_vector=True, fmap_finding_trials=10)
+        else:
+            self.update_fMAP()
+        if optimize_theta:
+            self.optimize_theta()
+            self.update_fMAP()
+            self.update_Sigma(self.theta)
+            self.update_Sigma_inv(self.theta)
+        if self.verbose:
+            print("Current theta is: " + str(self.theta) + " (Acq. = " + str(self.xi_acquisition_function) + ")")
+        if not init_skip:
+            if self.verbose:
+                print("Updating Lambda_MAP and posterior covariance...")
+            start = time.time()
+            try:
+                self._post = self.eng.posterior(self._dX, self.theta, self.kernel.__name__, self._dSigma_inv,
+                                                self.eng.dev(self.fMAP), self.m, want_P=False)
+                self._post_mean = self._post
+                self._invalidate("Lambda_MAP", "P", "Pinv")
+            except NotPositiveDefinite:
+                print("---!!!--- Posterior covariance matrix is not PSD ---!!!---")   # gp_model.py:119, keep the old one
+            if self.verbose:
+                print("... this took " + str(time.time() - start) + " seconds.")
+        if self.verbose:
+            print("Computing mu_star and x_star ...")
+        start = time.time()
+        if init_skip and not self.skip_xstaroptimization_during_initialization:
+            self.xstar, self.mustar, self.xstars_local = self.mu_star(mustar_finding_trials=1)
+        elif self.initialization_running and self.skip_xstaroptimization_during_initialization:
+            pass
+        elif self.last_iteration:
+            self.xstar, self.mustar, self.xstars_local = self.mu_star(mustar_finding_trials=20)
+        else:
+            self.xstar, self.mustar, self.xstars_local = self.mu_star()
+        if self.verbose:
+            print("... this took " + str(time.time() - start) + " seconds.")
+
+    # ------------------------------------------------------------------ predictions
+    def _mean_post(self):
+        if self._post_mean is None:
+            raise RuntimeError("update_model()/update_fMAP() must run before predictions")
+        return self._post_mean
+
+    def mu_Sigma_pred(self, X_pred):
+        if self._post is None or self._post.G is None:
+            raise RuntimeError("posterior covariance unavailable (skipped during initialisation, gp_model.py:106-107)")
+        mu, cov = self.eng.predict_cov(self._post, np.atleast_2d(X_pred), self.COVARIANCE_SHRINKAGE)
+        return mu.cpu().numpy(), cov.cpu().numpy()
+
+    def mu_pred(self, X_pred):
+        x = np.asarray(X_pred, dtype=float).reshape(1, self.D)
+        out = self.eng.predict(self._mean_post(), x, score=SCORE_MEAN, want_var=False, want_best=False)
+        return float(out["mu"].item())
+
+    def mu_pred_neq(self, X_pred):
+        return -self.mu_pred(X_pred)
+
+    def mu_pred_batch(self, X_pred):
+        """Posterior mean of many points in one launch (device tensor in, NumPy out)."""
+        out = self.eng.predict(self._mean_post(), X_pred, score=SCORE_MEAN, want_var=False, want_best=False)
+        return out["mu"].cpu().numpy()
+
+    # ------------------------------------------------------------------ maximiser of the posterior mean
+    def _argmax_mean(self, cand):
+        out = self.eng.predict(self._mean_post(), cand, score=SCORE_MEAN, want_mu=False, want_var=False)
+        return out["best_val"], out["best_idx"]
+
+    def _polish(self, x0):
+        """Bounded quasi-Newton polish; value and central-difference gradient of every iterate
+        come from ONE batched device evaluation of 2D+1 points."""
+        D, h = self.D, 1e-5
+
+        def fg(x):
+            P = np.repeat(x[None, :], 2 * D + 1, axis=0)
+            P[1:D + 1] += h * np.eye(D)
+            P[D + 1:] -= h * np.eye(D)
+            mu = self.mu_pred_batch(np.clip(P, 0.0, 1.0))
+            return -mu[0], -(mu[1:D + 1] - mu[D + 1:]) / (2 * h)
+
+        res = scipy.optimize.minimize(fg, x0, jac=True, method="L-BFGS-B", bounds=self.bounds,
+                                      options={"maxiter": 200})
+        return np.clip(res.x, 0.0, 1.0), -float(res.fun)
+
+    def mu_star(self, mustar_finding_trials=None):
+        trials = self.mustar_finding_trials if mustar_finding_trials is None else mustar_finding_trials
+        D = self.D
+        found = []
+        for t in range(trials):
+            cand = np.random.uniform(0.0, 1.0, (SEARCH_CANDIDATES, D))
+            if t == 0:
+                k = min(self.N, SEARCH_CANDIDATES // 2)
+                cand[:k] = self.X[np.random.permutation(self.N)[:k]]      # the design points themselves
+                if self.xstar is not None:
+                    cand[k] = self.xstar
+            val, idx = self._argmax_mean(cand)
+            x = cand[idx].copy()
+            for r in ZOOM_RADII:
+                loc = np.clip(x + r * (2.0 * np.random.uniform(size=(ZOOM_CANDIDATES, D)) - 1.0), 0.0, 1.0)
+                loc[0] = x
+                v2, i2 = self._argmax_mean(loc)
+                if v2 >= val:
+                    val, x = v2, loc[i2].copy()
+            xp, vp = self._polish(x)
+            if vp >= val:
+                x, val = xp, vp
+            found.append((val, x))
+        found.sort(key=lambda p: -p[0])
+        xstar = found[0][1].copy()
+        local = [found[0][1]]
+        for _, x in found[1:]:                                          # distinct maxima > 0.1 apart (gp_model.py:430)
+            if all(np.linalg.norm(x - y) > 1e-1 for y in local):
+                local.append(x)
+        xstars_local = np.vstack(local).reshape(-1, D)
+        return xstar.reshape(D,), self.mu_pred(xstar), xstars_local

@@ -1,0 +1,175 @@
+"""Drop-in Hsampler (src/random_fourier_sampler.py): random-Fourier-feature posterior samples of
+the utility and their maximisers, with the feature projection, the weight-space Laplace terms
+and the candidate scoring evaluated by the HIP kernels (ppbo_rff_project / _terms / _score).
+
+Differences in *cost*, not in results: the reference's weight-space Hessian is diagonal
+(:118-122) but is returned, inverted and sampled as a dense F x F matrix (:134-140, 207-213);
+here the diagonal is kept as a vector (the dense forms are still produced on request for
+attribute compatibility).  The L-BFGS-B multi-start of return_xstar (:143-176) is seeded by a
+batched on-device argmax over candidates.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import scipy.optimize
+
+from .engine import get_engine
+
+SCORE_CANDIDATES = 65536
+
+
+class Hsampler:
+    def __init__(self, gp_model, nFeatures=1000, engine=None):
+        self.eng = engine if engine is not None else getattr(gp_model, "eng", None) or get_engine()
+        self.nFeatures = nFeatures
+        self.b = None
+        self.W = None
+        self.D = gp_model.D
+        self.m = gp_model.m
+        self.X = gp_model.X
+        self.GP_xstar = gp_model.xstar
+        self.GP_xstars_local = gp_model.xstars_local
+        self.n_gausshermite_sample_points = gp_model.n_gausshermite_sample_points
+        self.obs_indices = gp_model.obs_indices
+        self.kernel = str(gp_model.kernel.__name__)
+        self.theta = gp_model.theta
+        self.phi_X = None
+        self.omega_MAP = None
+        self.covariance = None
+        self.covariance_inv = None
+        self.cov_diag = None
+        self.verbose = False
+        self._dPhi = None
+
+    # ---- basis -----------------------------------------------------------------
+    def generate_basis(self):
+        if self.kernel == "SE_kernel":                        # only the SE spectral density is supported (:40-42)
+            self.W = np.random.randn(self.nFeatures, self.D) / self.theta[1]
+        self.b = np.random.uniform(low=0, high=2 * np.pi, size=self.nFeatures)[:, None]
+
+    def _scale(self):
+        return np.sqrt(2.0 * self.theta[2] ** 2 / self.nFeatures)
+
+    def phiVec(self, x):
+        x = np.atleast_2d(np.asarray(x, dtype=float))
+        return self.eng.rff_project(x, self.W, self.b.ravel(), self.theta[2]).cpu().numpy()
+
+    def phi(self, x):
+        return self._scale() * np.cos(self.W @ np.asarray(x, dtype=float) + self.b.ravel())
+
+    def Dphi(self, x):
+        return -self._scale() * np.sin(self.W @ np.asarray(x, dtype=float) + self.b.ravel())[:, None] * self.W
+
+    def DDphi(self, x):
+        raise NotImplementedError
+
+    def update_phi_X(self):
+        self._dPhi = self.eng.rff_project(self.X, self.W, self.b.ravel(), self.theta[2])
+        self.phi_X = self._dPhi.cpu().numpy()
+
+    # ---- weight-space Laplace terms ------------------------------------------------
+    def _terms(self, omega, theta):
+        return self.eng.rff_terms(self._dPhi, omega, self.m, theta[0])
+
+    def S(self, omega, theta):
+        return self._terms(omega, theta)[0]
+
+    def S_grad(self, omega, theta):
+        return self._terms(omega, theta)[1].cpu().numpy()
+
+    def S_hessian_diag(self, omega, theta):
+        return self._terms(omega, theta)[2].cpu().numpy()
+
+    def S_hessian(self, omega, theta):
+        return np.diag(self.S_hessian_diag(omega, theta))
+
+    def update_omega_MAP(self):
+        """Maximise S from a standard-normal start (:124-132).  The Hessian is diagonal, so the
+        trust-region Newton of the reference reduces to per-coordinate safeguarded Newton steps."""
+        omega = np.random.randn(self.nFeatures)
+        start = time.time()
+        S, g, h = self._terms(omega, self.theta)
+        g, h = g.cpu().numpy(), h.cpu().numpy()
+        radius = 1.0
+        for _ in range(500):
+            if np.linalg.norm(g) < 1e-6:
+                break
+            curv = np.maximum(-h, 1e-12)                     # -S is convex where h < 0
+            step = g / curv
+            nrm = np.linalg.norm(step)
+            if nrm > radius:
+                step *= radius / nrm
+            Sn, gn, hn = self._terms(omega + step, self.theta)
+            pred = g @ step - 0.5 * step @ (curv * step)
+            rho = (Sn - S) / pred if pred > 0 else -1.0
+            if rho < 0.25:
+                radius *= 0.25
+            elif rho > 0.75 and nrm >= radius:
+                radius = min(2.0 * radius, 1000.0)
+            if rho > 0.15:
+                omega, S, g, h = omega + step, Sn, gn.cpu().numpy(), hn.cpu().numpy()
+            if radius < 1e-14:
+                break
+        if self.verbose:
+            print("... this took " + str(time.time() - start) + " seconds.")
+        self.omega_MAP = omega
+
+    def update_covariancematrix(self):
+        hd = -self.S_hessian_diag(self.omega_MAP, self.theta)
+        if np.any(hd <= 0):
+            print("---!!!--- Posterior covariance matrix is not PSD ---!!!---")
+            return
+        self.cov_diag = 1.0 / hd
+        if self.nFeatures <= 4096:                            # dense forms only for attribute compatibility
+            self.covariance_inv = np.diag(hd)
+            self.covariance = np.diag(self.cov_diag)
+
+    def sample_omega(self):
+        if self.cov_diag is None:
+            print("Omega sampler error! Omega MAP-estimate was used instead.")
+            return self.omega_MAP
+        return self.omega_MAP + np.sqrt(self.cov_diag) * np.random.standard_normal(self.nFeatures)
+
+    # ---- maximiser of one posterior sample --------------------------------------------
+    def score_candidates(self, Xc, omega):
+        """phi(x)^T omega for many candidates on the device; returns (scores, best value, best index)."""
+        sc, bv, bi = self.eng.rff_score(Xc, self.W, self.b.ravel(), self.theta[2], omega)
+        return sc.cpu().numpy(), bv, bi
+
+    def return_xstar(self, omega):
+        start = time.time()
+        D = self.D
+        cand = np.random.uniform(0, 1, (SCORE_CANDIDATES, D))
+        loc = np.atleast_2d(self.GP_xstars_local)
+        k = min(len(loc) * 64, SCORE_CANDIDATES // 4)
+        cand[:k] = np.clip(loc[np.random.randint(len(loc), size=k)] + 0.01 * np.random.uniform(0, 1, (k, D)), 0, 1)
+        _, _, bi = self.eng.rff_score(cand, self.W, self.b.ravel(), self.theta[2], omega, want_score=False)
+        best_x, best_f = None, -1e10
+        for x0 in (cand[bi], cand[np.random.randint(k)]):
+            res = scipy.optimize.minimize(lambda x: -float(self.phi(x) @ omega), x0=x0, method="L-BFGS-B",
+                                          bounds=((0, 1),) * D, jac=lambda x: -(self.Dphi(x).T @ omega),
+                                          options={"disp": False, "maxiter": 5000})
+            f = float(self.phi(res.x) @ omega)
+            if f > best_f and np.all((res.x >= 0) & (res.x <= 1)):
+                best_x, best_f = res.x, f
+        if self.verbose:
+            print("Optimization of f_approx took " + str(time.time() - start) + " seconds.")
+        return best_x
+
+    def return_xstar_for_dim(self, omega, dim, x_ref):
+        x_ref = np.array(x_ref, dtype=float)
+        grid = np.tile(x_ref, (4096, 1))
+        grid[:, dim - 1] = np.linspace(0, 1, 4096)
+        _, _, bi = self.eng.rff_score(grid, self.W, self.b.ravel(), self.theta[2], omega, want_score=False)
+        return grid[bi]
+
+    def sample_xstar(self):
+        xstar = None
+        while xstar is None:
+            xstar = self.return_xstar(self.sample_omega())
+        return xstar
+
+    def sample_xstar_for_dim(self, dim, x_ref):
+        return self.return_xstar_for_dim(self.sample_omega(), dim, x_ref)

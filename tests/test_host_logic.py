@@ -1,0 +1,74 @@
+"""CPU-only checks of the host side of the drop-in (design shaping, settings, dispatcher bookkeeping)."""
+import numpy as np
+import pytest
+
+from ppbo_amd.feedback_processing import FeedbackProcessing
+from ppbo_amd.misc import alpha_bounds, hypercube_corners
+from ppbo_amd.ppbo_settings import PPBO_settings
+
+
+def _obs_rows(n_q, D, lo, hi, seed=0):
+    rs = np.random.RandomState(seed)
+    rows = []
+    for q in range(n_q):
+        d = q % D
+        xi = np.zeros(D); xi[d] = 1.0
+        x = lo + rs.rand(D) * (hi - lo); x[d] = 0.0
+        a = lo[d] + rs.rand() * (hi[d] - lo[d])
+        rows.append(np.concatenate([a * xi + x, xi, [a]]))
+    return np.array(rows)
+
+
+@pytest.mark.parametrize("dist", ["equispaced", "Cauchy", "TGN"])
+def test_design_matrix_contract(dist):
+    D, m = 3, 7
+    bounds = ((-3, 3), (-2, 2), (0, 10))
+    lo = np.array([b[0] for b in bounds], float); hi = np.array([b[1] for b in bounds], float)
+    Xo = _obs_rows(5, D, lo, hi)
+    np.random.seed(1)
+    fp = FeedbackProcessing(D, m, bounds, dist, 0.4)
+    fp.initialize_data(Xo[:3])
+    fp.update_data(Xo[:4])
+    fp.update_data(Xo[:5])
+    assert fp.N == 5 * (m + 1) and fp.X.shape == (fp.N, D)
+    assert fp.obs_indices == [q * (m + 1) for q in range(5)]
+    assert fp.latest_obs_indices == [(i // (m + 1)) * (m + 1) for i in range(fp.N)]
+    assert len(fp.pseudobs_indices) == 5 * m
+    assert fp.X.min() >= -1e-12 and fp.X.max() <= 1 + 1e-12
+    for q in range(5):
+        blk = fp.X[q * (m + 1):(q + 1) * (m + 1)]
+        d = q % D
+        assert np.allclose(blk[0], fp.scale(Xo[q, :D]))
+        others = [k for k in range(D) if k != d]
+        assert np.allclose(blk[1:, others], blk[0, others])          # pseudo-observations stay on the line
+        assert len(np.unique(blk[1:, d])) == m                         # m distinct grid points
+    assert np.allclose(fp.unscale(fp.scale(Xo[:, :D])), Xo[:, :D])
+    z = np.array([[0.0, 1.0, 0.0]])
+    assert np.array_equal(fp.unscale(z, retain_0_values=True) == 0, z == 0)
+
+
+def test_xi_grid_scaled_line():
+    fp = FeedbackProcessing(4, 5, ((0, 1),) * 4, "equispaced", 0.4)
+    np.random.seed(0)
+    g = fp.xi_grid(xi=np.array([0, 1.0, 0, 0]), x=np.array([0.2, 0.0, 0.4, 0.6]), m=70, is_scaled=True)
+    assert g.shape == (70, 4) and np.all(np.diff(g[:, 1]) > 0) and g[:, 1].min() >= 0 and g[:, 1].max() <= 1
+    assert np.allclose(g[:, [0, 2, 3]], [0.2, 0.4, 0.6])
+
+
+def test_alpha_bounds_and_corners():
+    lo, hi = alpha_bounds([1.0, 0, -0.5], [-3, -2, -1], [3, 2, 1])
+    assert np.isclose(lo, -2.0) and np.isclose(hi, 2.0)
+    c = hypercube_corners(((-3, 3), (-2, 2)))
+    assert c.shape == (4, 2) and {tuple(r) for r in c} == {(-3, -2), (-3, 2), (3, -2), (3, 2)}
+
+
+def test_settings_derivations():
+    s = PPBO_settings(D=6, bounds=((0, 1),) * 6, xi_acquisition_function="PCD", m=31, verbose=False)
+    assert s.dim_query_prev_iter == 6 and s.x_acquisition_function == "exploit" and s.n_pseudoobservations == 31
+    s = PPBO_settings(D=6, bounds=((0, 1),) * 6, xi_acquisition_function="EI", verbose=False)
+    assert s.xi_dims_prev_iter == [0, 1] and s.x_acquisition_function == "none"
+    s = PPBO_settings(D=2, bounds=((0, 1),) * 2, xi_acquisition_function="EXR", verbose=False)
+    assert s.xi_dims_prev_iter == [1]
+    s = PPBO_settings(D=3, bounds=((0, 1),) * 3, xi_acquisition_function="COORDINATE-VARMAX", verbose=False)
+    assert s.x_acquisition_function == "varmax" and s.dim_query_prev_iter == 3
+    assert s.fMAP_optimizer == "trust-exact" and s.mc_samples == 150 and s.n_gausshermite_sample_points == 200
