@@ -192,6 +192,24 @@ __global__ __launch_bounds__(1024) void step_kernel(const double* __restrict__ u
   }
 }
 
+// out[0] = sum_i p_i (v1_i + v2_i): the change of the quadratic term f'Sf between f and f+p is
+// p'(Sf) + 1/2 p'Sp = 1/2 p'(v1+v2) -- evaluated from SMALL quantities instead of subtracting two
+// O(1e1) numbers that each carry cond(Sigma)*eps of summation noise.
+__global__ __launch_bounds__(1024) void pdot2_kernel(const double* __restrict__ p, const double* __restrict__ v1,
+                                                     const double* __restrict__ v2, int N, double* __restrict__ out) {
+  __shared__ double sh[16];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < N; i += 1024) a += p[i] * (v1[i] + v2[i]);
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    *out = t;
+  }
+}
+
 // G[i][j] = (R Lambda)[i][j] for the star-structured Lambda; thread = (row i, star q)
 __global__ __launch_bounds__(256) void g_build_kernel(const double* __restrict__ R, int N, int mblk,
                                                       const double* __restrict__ lam_diag,
@@ -215,6 +233,7 @@ __global__ __launch_bounds__(256) void g_build_kernel(const double* __restrict__
 struct Vecs {  // one evaluation point
   double *f, *v, *beta, *ld, *lo, *g;
   double fSf, gn2, Tlik;
+  double pv;   // p.(v_prev + v_this) when evaluated as a trial point
 };
 
 struct FitWork {
@@ -229,18 +248,20 @@ struct FitWork {
   int* d_info;
 };
 
-int eval_point(FitWork& W, Vecs& P) {
+int eval_point(FitWork& W, Vecs& P, const double* step = nullptr, const double* v_prev = nullptr) {
   // v = Sinv f ; laplace terms ; g ; scalars -> host
   if (int rc = ppbo_gemv_async(W.ctx, W.Sinv, W.N, W.N, P.f, P.v, 0, 0, W.s)) return rc;
+  if (step) pdot2_kernel<<<1, 1024, 0, W.s>>>(step, v_prev, P.v, W.N, W.sc + 3);
   laplace_kernel<<<(W.n_q + 3) / 4, 256, 0, W.s>>>(P.f, W.N, W.mblk, W.n_q, W.sigma, W.tq, P.beta, P.ld, P.lo);
   tlik_reduce_kernel<<<1, 1024, 0, W.s>>>(W.tq, W.n_q, W.m, W.sc + 2);
   grad_kernel<<<1, 1024, 0, W.s>>>(P.f, P.v, P.beta, W.N, P.g, nullptr, W.sc);
   PPBO_LAUNCH_CHECK(W.ctx);
-  PPBO_HIP_CHECK(W.ctx, hipMemcpyAsync(W.hsc, W.sc, 3 * sizeof(double), hipMemcpyDeviceToHost, W.s));
+  PPBO_HIP_CHECK(W.ctx, hipMemcpyAsync(W.hsc, W.sc, 4 * sizeof(double), hipMemcpyDeviceToHost, W.s));
   PPBO_HIP_CHECK(W.ctx, hipStreamSynchronize(W.s));
   P.fSf = W.hsc[0];
   P.gn2 = W.hsc[1];
   P.Tlik = W.hsc[2];
+  P.pv = step ? W.hsc[3] : 0.0;
   return 0;
 }
 
@@ -414,8 +435,10 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
     // (H + lam I) p = -g  =>  p'Hp = -g'p - lam |p|^2
     const double pred = -0.5 * gtp + 0.5 * lam_used * pn * pn;
     if (!(pred > 0.0)) break;
-    if (int rc = eval_point(W, T)) return rc;
-    const double rho = (phi_of(C) - phi_of(T)) / pred;
+    if (int rc = eval_point(W, T, W.p, C.v)) return rc;
+    // phi(f) - phi(f+p) = -1/2 p'(Sf + S(f+p)) + (Tlik(f+p) - Tlik(f)), from small quantities
+    const double actual = -0.5 * T.pv + (T.Tlik - C.Tlik);
+    const double rho = actual / pred;
     const double old_radius = radius;
     if (!(rho >= 0.25)) radius *= 0.25;
     else if (rho > 0.75 && boundary) radius = std::fmin(2.0 * radius, rmax);
