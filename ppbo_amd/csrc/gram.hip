@@ -128,25 +128,23 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ X,
   }
 }
 
-// SE / RQ Gram tile with the inner products on the fp64 matrix cores:
-//   r^2 = |x_i|^2 + |x_j|^2 - 2 x_i.x_j  (the reference's own formula, kernels.py:7-10, clipped at 0),
-// x_i.x_j by v_mfma_f64_16x16x4_f64 over the zero-padded dimension, so the VALU only does the
-// norm combine + exp.  Wave w owns rows 16w..16w+15 of the 64x64 tile (4 MFMA column tiles).
-// The finished tile is staged in LDS (aliasing the dead operand panels) so that both the tile
-// and its mirror leave as 512-byte row segments.
-template <int KID>
+// SE / RQ Gram tile with the whole squared distance on the fp64 matrix cores.  Rows are
+// augmented so that one MFMA chain yields r^2 directly (the reference's expansion formula,
+// kernels.py:7-10, clipped at 0):
+//   a_i = ( x_i , |x_i|^2 , 1 , 0.. )      b_j = ( -2 x_j , 1 , |x_j|^2 , 0.. )      a_i . b_j = r_ij^2
+// DP = D padded to a multiple of 4 (compile time), KA = DP + 4 the augmented depth.  The panel
+// loads, the fragment reads and the MFMA chain are fully unrolled: one HBM round trip, one LDS
+// round trip, KA/4 * 4 MFMAs per wave, then clip + exp + shrink.  Wave w owns rows 16w..16w+15.
+// The finished tile is staged in LDS (aliasing the dead panels) so that the tile and its mirror
+// both leave as full 512-byte row segments.
+template <int KID, int DP>
 __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict__ X, int N, int D, KernParams p,
                                                          double shrink, double* __restrict__ Sigma, int nt) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int Dp = (D + 3) & ~3, LD = Dp + 2;
-  const int tile_doubles = TS * TP;
-  const int pan_doubles = 2 * TS * LD;
-  const int body = tile_doubles > pan_doubles ? tile_doubles : pan_doubles;
+  constexpr int KA = DP + 4, LD = KA + 2;
   double* Xa = smem;              // [64][LD]
   double* Xb = smem + TS * LD;    // [64][LD]
   double* Tt = smem;              // [64][TP] (aliases the panels once the MFMAs are done)
-  double* na = smem + body;       // [64]
-  double* nb = na + TS;           // [64]
 
   const int t = blockIdx.x;
   const double q = 2.0 * nt + 1.0;
@@ -156,86 +154,98 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
   const int bj = bi + (t - (bi * nt - bi * (bi - 1) / 2));
   const int i0 = bi * TS, j0 = bj * TS;
 
-  // coalesced panel loads (64 rows of X are one contiguous 64*D block), zero padding
-  for (int e = threadIdx.x; e < TS * Dp; e += 256) {
-    const int r = e / Dp, d = e - r * Dp;
-    Xa[r * LD + d] = (d < D && i0 + r < N) ? X[(size_t)(i0 + r) * D + d] : 0.0;
-    Xb[r * LD + d] = (d < D && j0 + r < N) ? X[(size_t)(j0 + r) * D + d] : 0.0;
+  // 4 lanes per row: each loads DP/4 elements of both panels, norms by two xor-shuffles
+  {
+    constexpr int Q = DP / 4;
+    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+    double xa[Q], xb[Q];
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      const int d = part * Q + k;
+      xa[k] = (d < D && i0 + r < N) ? X[(size_t)(i0 + r) * D + d] : 0.0;
+      xb[k] = (d < D && j0 + r < N) ? X[(size_t)(j0 + r) * D + d] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+      sa += xa[k] * xa[k];
+      sb += xb[k] * xb[k];
+      Xa[r * LD + part * Q + k] = xa[k];
+      Xb[r * LD + part * Q + k] = -2.0 * xb[k];
+    }
+    sa += __shfl_xor(sa, 1, 64); sa += __shfl_xor(sa, 2, 64);
+    sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64);
+    // augmentation columns DP..DP+3, one per lane of the row quad
+    Xa[r * LD + DP + part] = (part == 0) ? sa : ((part == 1) ? 1.0 : 0.0);
+    Xb[r * LD + DP + part] = (part == 0) ? 1.0 : ((part == 1) ? sb : 0.0);
   }
   __syncthreads();
-  if (threadIdx.x < 2 * TS) {
-    const double* row = (threadIdx.x < TS ? Xa : Xb) + (threadIdx.x & (TS - 1)) * LD;
-    double s = 0.0;
-    for (int d = 0; d < Dp; ++d) s += row[d] * row[d];
-    na[threadIdx.x] = s;          // na | nb are contiguous
-  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double4_t acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
-  for (int kk = 0; kk < Dp; kk += 4) {
-    const double a = Xa[(w * 16 + lr) * LD + kk + lk];
+  {
+    double af[KA / 4], bf[4][KA / 4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double b = Xb[(j * 16 + lr) * LD + kk + lk];
-      acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
-    }
+    for (int kk = 0; kk < KA / 4; ++kk) af[kk] = Xa[(w * 16 + lr) * LD + kk * 4 + lk];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kk = 0; kk < KA / 4; ++kk) bf[j][kk] = Xb[(j * 16 + lr) * LD + kk * 4 + lk];
+#pragma unroll
+    for (int kk = 0; kk < KA / 4; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[j][kk], acc[j], 0, 0, 0);
   }
-  __syncthreads();   // panels are dead from here; norms are visible
+  __syncthreads();   // panels are dead from here
   const double one_minus = 1.0 - shrink;
   const double diagv = one_minus * p.sf2 + shrink * p.sf2;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int col = j * 16 + lr;
-    const double nj = nb[col];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = w * 16 + lk + 4 * r;
-      double r2 = na[row] + nj - 2.0 * acc[j][r];
+      double r2 = acc[j][r];
       r2 = r2 > 0.0 ? r2 : 0.0;
       const double k = kern_finish<KID>(r2, p);
       Tt[row * TP + col] = ((i0 + row) == (j0 + col)) ? diagv : one_minus * k;
     }
   }
   __syncthreads();
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  // stores: lane = one 16-byte column pair, 32 lanes = one full 512-byte row segment
+  const int c2 = (threadIdx.x & 31) * 2, r0 = threadIdx.x >> 5;
   const bool vec_ok = ((N & 1) == 0);
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int r = ty * 4 + a;
-    const int gi = i0 + r;
+  for (int a = 0; a < 8; ++a) {
+    const int r = a * 8 + r0;
+    const int gi = i0 + r, gj = j0 + c2;
     if (gi >= N) continue;
-    const int gj = j0 + tx * 4;
-    const double* src = Tt + r * TP + tx * 4;
+    double2 v = *reinterpret_cast<const double2*>(Tt + r * TP + c2);
+    if (bi == bj) {   // diagonal tile: (acc + n_i) + n_j is not bitwise (acc + n_j) + n_i -> mirror the upper half
+      if (r > c2) v.x = Tt[c2 * TP + r];
+      if (r > c2 + 1) v.y = Tt[(c2 + 1) * TP + r];
+    }
     double* dst = Sigma + (size_t)gi * N + gj;
-    if (vec_ok && gj + 3 < N) {
-      *reinterpret_cast<double2*>(dst) = *reinterpret_cast<const double2*>(src);
-      *reinterpret_cast<double2*>(dst + 2) = *reinterpret_cast<const double2*>(src + 2);
-    } else {
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        if (gj + b < N) dst[b] = src[b];
+    if (vec_ok && gj + 1 < N) *reinterpret_cast<double2*>(dst) = v;
+    else {
+      if (gj < N) dst[0] = v.x;
+      if (gj + 1 < N) dst[1] = v.y;
     }
   }
   if (bi == bj) return;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int r = ty * 4 + a;       // row of the mirrored tile = column of Tt
-    const int gi = j0 + r;
+  for (int a = 0; a < 8; ++a) {
+    const int r = a * 8 + r0;           // row of the mirrored tile = column of Tt
+    const int gi = j0 + r, gj = i0 + c2;
     if (gi >= N) continue;
-    const int gj = i0 + tx * 4;
-    double v[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) v[b] = Tt[(tx * 4 + b) * TP + r];
+    const double vx = Tt[c2 * TP + r], vy = Tt[(c2 + 1) * TP + r];
     double* dst = Sigma + (size_t)gi * N + gj;
-    if (vec_ok && gj + 3 < N) {
-      *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
-      *reinterpret_cast<double2*>(dst + 2) = make_double2(v[2], v[3]);
-    } else {
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        if (gj + b < N) dst[b] = v[b];
+    if (vec_ok && gj + 1 < N) *reinterpret_cast<double2*>(dst) = make_double2(vx, vy);
+    else {
+      if (gj < N) dst[0] = vx;
+      if (gj + 1 < N) dst[1] = vy;
     }
   }
 }
@@ -290,8 +300,6 @@ int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, con
   static bool attr_done = false;
   if (!attr_done) {   // D up to 64 needs more than the default 64 KB of dynamic LDS
     const int cap = 112 * 1024;
-    (void)hipFuncSetAttribute((const void*)gram_mfma_kernel<PPBO_KERNEL_SE>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void*)gram_mfma_kernel<PPBO_KERNEL_RQ>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     (void)hipFuncSetAttribute((const void*)gram_kernel<PPBO_KERNEL_CAMPHOR>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     (void)hipFuncSetAttribute((const void*)crosscov_kernel<PPBO_KERNEL_SE>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     (void)hipFuncSetAttribute((const void*)crosscov_kernel<PPBO_KERNEL_RQ>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
@@ -299,11 +307,31 @@ int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, con
   }
   PpboProfScope pf(ctx, ppbo_ctx::PF_GRAM, s);
   if (kernel_id != PPBO_KERNEL_CAMPHOR) {
-    const int Dp = (D + 3) & ~3, LD = Dp + 2;
-    const int body = (TS * TP > 2 * TS * LD) ? TS * TP : 2 * TS * LD;
-    const size_t lds = (size_t)(body + 2 * TS) * sizeof(double);
-    if (kernel_id == PPBO_KERNEL_SE) gram_mfma_kernel<PPBO_KERNEL_SE><<<nblk, 256, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);
-    else gram_mfma_kernel<PPBO_KERNEL_RQ><<<nblk, 256, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);
+#define GM_LAUNCH(DPV)                                                                                       \
+  do {                                                                                                       \
+    constexpr int LDv = DPV + 6;                                                                             \
+    constexpr int body = (TS * TP > 2 * TS * LDv) ? TS * TP : 2 * TS * LDv;                                  \
+    const size_t lds = (size_t)body * sizeof(double);                                                        \
+    if (kernel_id == PPBO_KERNEL_SE) {                                                                       \
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gram_mfma_kernel<PPBO_KERNEL_SE, DPV>,     \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      gram_mfma_kernel<PPBO_KERNEL_SE, DPV><<<nblk, 256, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);       \
+    } else {                                                                                                 \
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gram_mfma_kernel<PPBO_KERNEL_RQ, DPV>,     \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      gram_mfma_kernel<PPBO_KERNEL_RQ, DPV><<<nblk, 256, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);       \
+    }                                                                                                        \
+  } while (0)
+    if (D <= 4) GM_LAUNCH(4);
+    else if (D <= 8) GM_LAUNCH(8);
+    else if (D <= 12) GM_LAUNCH(12);
+    else if (D <= 16) GM_LAUNCH(16);
+    else if (D <= 20) GM_LAUNCH(20);
+    else if (D <= 24) GM_LAUNCH(24);
+    else if (D <= 32) GM_LAUNCH(32);
+    else if (D <= 48) GM_LAUNCH(48);
+    else GM_LAUNCH(64);
+#undef GM_LAUNCH
   } else {
     const size_t lds = ((size_t)2 * D * TS + (size_t)TS * TP) * sizeof(double);
     gram_kernel<PPBO_KERNEL_CAMPHOR><<<nblk, 256, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);
