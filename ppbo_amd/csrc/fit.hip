@@ -362,6 +362,8 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
   double radius = 1.0;
   const double rmax = 1000.0, eta = 0.15, k_easy = 0.1;
   double lam_lb_prev = 0.0;
+  double prev_lam = 0.0, prev_radius = 1.0;
+  bool prev_boundary = false;
   bool shrink = false, h_changed = true;
   double st_mindiag = 0, st_gmax = 0, st_gmin = 0, st_fro = 0, st_inf = 0;
   int it = 0, nchol = 0;
@@ -389,6 +391,12 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
     double ub = std::fmax(0.0, gnorm / radius + std::fmin(-st_gmin, hn));
     if (shrink) lb = std::fmax(lb, lam_lb_prev);
     double lam = (lb == 0.0) ? 0.0 : std::fmax(std::sqrt(lb * ub), lb + 0.01 * (ub - lb));
+    // Warm start (not in SciPy): the multiplier that hit the previous radius, rescaled for the new
+    // radius, is a far better guess than the Gershgorin geometric mean (Sigma^-1 has 1e7-size
+    // off-diagonals, so those bounds are loose).  lam = 0 is still tried first whenever it is not ruled out.
+    double warm = 0.0;
+    if (prev_lam > 0.0 && prev_boundary) warm = prev_lam * (prev_radius / radius);
+    if (lb > 0.0 && warm > lb && warm < ub) { lam = warm; warm = 0.0; }
     bool boundary = true, have_step = false;
     double pn = 0.0, gtp = 0.0, lam_used = 0.0;
     for (int inner = 0; inner < 80; ++inner) {
@@ -404,8 +412,10 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
       PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
       if (info != 0) {
         lb = std::fmax(lb, lam);
+        if (lb == 0.0) lb = 1e-14 * std::fmax(st_inf, 1e-300);   // lam = 0 is ruled out from now on
         if (ub <= lb) ub = 2.0 * lb + 1e-12;
-        lam = std::fmax(std::sqrt(lb * ub), lb + 0.01 * (ub - lb));
+        if (warm > lb && warm < ub) { lam = warm; warm = 0.0; }
+        else lam = std::fmax(std::sqrt(lb * ub), lb + 0.01 * (ub - lb));
         continue;
       }
       if (int rc = ppbo_trtri_async(ctx, W.H, N, N, W.Linv, N, s)) return rc;
@@ -425,13 +435,21 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
       if (std::fabs(pn - radius) <= k_easy * radius) break;
       double lam_new = lam + (pn * pn / qn2) * (pn - radius) / radius;
       if (pn < radius) ub = lam; else lb = lam;
-      if (!(lb < lam_new && lam_new < ub)) lam_new = std::fmax(std::sqrt(lb * ub), lb + 0.01 * (ub - lb));
+      if (!(lb < lam_new && lam_new < ub)) {
+        // the secular-equation Newton step left the bracket; if lam = 0 is still possible (no failed
+        // factorization there) and the step is inside the region, the interior Newton step is next
+        if (lb == 0.0 && pn < radius) lam_new = 0.0;
+        else lam_new = std::fmax(std::sqrt(lb * ub), lb + 0.01 * (ub - lb));
+      }
       if (lam_new < 0.0) lam_new = 0.0;
       if (lam_new == lam) break;
       lam = lam_new;
     }
     lam_lb_prev = lb;
     if (!have_step) break;
+    prev_lam = lam_used;
+    prev_radius = radius;
+    prev_boundary = boundary;
     // (H + lam I) p = -g  =>  p'Hp = -g'p - lam |p|^2
     const double pred = -0.5 * gtp + 0.5 * lam_used * pn * pn;
     if (!(pred > 0.0)) break;
