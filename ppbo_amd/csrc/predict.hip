@@ -120,12 +120,23 @@ __global__ __launch_bounds__(C::NT, MINW) void quadform_kernel(const double* __r
                                                                int tri_block, double* __restrict__ slab, int ntm,
                                                                int ntn, int swizzle) {
   int id = blockIdx.x;
-  if (swizzle) {                       // XCD-aware: consecutive logical ids share an XCD / L2
+  if (swizzle & 1) {                   // XCD-aware: consecutive logical ids share an XCD / L2
     const int per = gridDim.x >> 3;
     id = (id & 7) * per + (id >> 3);
   }
-  // row tile fastest, heaviest (largest K range) first
-  const int mt = ntm - 1 - (id % ntm), nt = id / ntm;
+  int mt, nt;
+  if (swizzle & 2) {                   // candidate tile fastest: co-resident workgroups share one G row panel
+    const int ch = swizzle >> 2;       // optional: candidate tiles in chunks of ch (K* chunk stays in the Infinity Cache)
+    if (ch > 0 && ntn % ch == 0) {
+      const int per_chunk = ntm * ch;
+      const int c = id / per_chunk, rem = id % per_chunk;
+      mt = ntm - 1 - (rem / ch); nt = c * ch + (rem % ch);
+    } else {
+      mt = ntm - 1 - (id / ntn); nt = id % ntn;
+    }
+  } else {                             // row tile fastest, heaviest (largest K range) first: share one K* panel
+    mt = ntm - 1 - (id % ntm); nt = id / ntm;
+  }
   const int m0 = mt * C::BM, n0 = nt * C::BN;
   const int e = ((m0 + C::BM + tri_block - 1) / tri_block) * tri_block;
   const int kend = e < N ? e : N;
@@ -177,7 +188,9 @@ int launch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, int
   }
   const int ntm = (N + C::BM - 1) / C::BM, ntn = (Mc + C::BN - 1) / C::BN;
   const int grid = ntm * ntn;
-  const int swz = (grid % 8 == 0 && grid >= 64) ? 1 : 0;
+  static int order = -1;
+  if (order < 0) { const char* e = getenv("PPBO_QF_ORDER"); order = e ? atoi(e) : 258; }   // candidate-tile fastest in chunks of 64 tiles (measured best)
+  const int swz = ((grid % 8 == 0 && grid >= 64) ? (order & 1) : 0) | (order & ~1);
   // every tile in bounds, 16-byte aligned, and every K range a multiple of 16?
   const bool fast = (N % C::BM == 0) && (Mc % C::BN == 0) && (N % 2 == 0) && (ldk % 2 == 0) && (mblk % 16 == 0 || mblk == 1 || (C::BM % mblk == 0)) &&
                     ((reinterpret_cast<uintptr_t>(G) & 15) == 0) && ((reinterpret_cast<uintptr_t>(Kt) & 15) == 0);
