@@ -314,3 +314,71 @@ def test_full_size_c3_properties(eng, golden):
     sf2 = float(g["theta"][2]) ** 2
     assert rel(host(full["mu"])[idx], mu0) < 1e-6
     assert np.abs(host(full["var"])[idx] - var0).max() <= 1e-6 * sf2
+
+
+# ---------------------------------------------------------------- general m / sizes without a reference fixture
+@pytest.mark.parametrize("m,n_q,D,kernel", [(1, 40, 2, "SE_kernel"), (5, 13, 3, "RQ_kernel"), (25, 6, 2, "SE_kernel"),
+                                            (25, 25, 2, "SE_kernel"), (63, 3, 4, "SE_kernel")])
+def test_pipeline_general_m_vs_oracle(eng, m, n_q, D, kernel):
+    """Whole device pipeline (Gram, inverse, fit, posterior, predict, covariance) against the oracle for
+    star sizes that do not divide the 128-row MFMA tiles (the reference's default is m=25)."""
+    th = [0.2, 0.3, 0.5]
+    X = orc.synthetic_design(n_q, D, m=m, seed=3)
+    N = X.shape[0]
+    S0 = orc.gram(X, th, kernel)
+    Sinv0 = orc.pd_inverse(S0)
+    f_init = np.random.default_rng(2).multivariate_normal(np.zeros(N), S0, method="cholesky")
+    f0, _ = orc.fit_fmap_trust_exact(f_init, Sinv0, m, th[0], gtol=1e-9)
+    S = eng.gram(X, th, kernel)
+    Sinv = eng.pd_inverse(S)
+    assert rel(host(Sinv), Sinv0) < 1e-6
+    fm, st = eng.fit_fmap(Sinv, f_init, m, th[0], gtol=1e-8)
+    assert np.abs(host(fm) - f0).max() <= 5e-6 * np.abs(f0).max()     # two optimisers, cond(Sigma) ~ 1e7
+    post = eng.posterior(X, th, kernel, Sinv, f0, m, want_P=True)
+    P0 = orc.posterior_covariance(Sinv0, f0, m, th[0])
+    assert rel(host(post.P), P0) < 1e-6
+    Xc = np.random.default_rng(4).random((300, D))
+    A0 = orc.variance_operator(Sinv0, P0, faithful=False, lam=orc.lambda_dense(f0, m, th[0]))
+    mu0, var0 = orc.predict_mean_var(Xc, X, th, Sinv0 @ f0, A0, kernel)
+    out = eng.predict(post, Xc)
+    assert rel(host(out["mu"]), mu0) < 1e-7
+    assert np.abs(host(out["var"]) - var0).max() <= 1e-7 * th[2] ** 2
+    mu1, cov1 = eng.predict_cov(post, Xc[:70])
+    _, cov0 = orc.mu_sigma_pred(Xc[:70], X, th, Sinv0, f0, P0, kernel, faithful=False, A=A0)
+    assert np.abs(host(cov1) - cov0).max() <= 1e-7 * th[2] ** 2
+
+
+def test_c5_size_camphor_properties(eng):
+    """BASELINE config 5 shape: camphor-copper kernel, D=6, N=4096 (m=31).  No reference fixture at this
+    size (the reference's own fit takes hours): device fit, then prediction against the oracle on a subsample."""
+    th, m, D, n_q = [0.05, 0.26, 0.1], 31, 6, 128
+    kernel = "camphor_copper_kernel"
+    X = orc.synthetic_design(n_q, D, m=m, seed=5)
+    N = X.shape[0]
+    S = eng.gram(X, th, kernel)
+    Sh = host(S)
+    assert np.array_equal(Sh, Sh.T)
+    ii = np.random.default_rng(0).integers(0, N, 300)
+    Kraw = orc.cross_cov(X[ii], X[ii], th, kernel)
+    off = ~np.eye(len(ii), dtype=bool) & (ii[:, None] != ii[None, :])
+    assert np.abs(Sh[np.ix_(ii, ii)][off] - (1 - 1e-6) * Kraw[off]).max() <= 1e-12 * th[2] ** 2
+    Sinv = eng.pd_inverse(S)
+    f_init = host(eng.dgemv(eng.potrf_(S.clone()), np.random.default_rng(2).standard_normal(N), lower=True))
+    fm, st = eng.fit_fmap(Sinv, f_init, m, th[0], gtol=1e-5)
+    assert st["converged"]
+    post = eng.posterior(X, th, kernel, Sinv, fm, m, want_P=True)
+    Xc = np.random.default_rng(1).random((4096, D))
+    out = eng.predict(post, Xc)
+    # oracle with the device's Sigma^-1 / P (an N=4096 CPU inverse is the slow part; identities are what is checked)
+    sub = np.random.default_rng(3).choice(4096, 64, replace=False)
+    K = orc.cross_cov(X, Xc[sub], th, kernel)
+    f = host(fm)
+    Sinv_h, P_h = host(Sinv), host(post.P)
+    mu0 = K.T @ (Sinv_h @ f)
+    lam = orc.lambda_dense(f, m, th[0])
+    W = -lam
+    A0 = W - W @ P_h @ W
+    var0 = th[2] ** 2 - np.einsum("ij,ij->j", K, A0 @ K)
+    assert rel(host(out["mu"])[sub], mu0) < 1e-6
+    assert np.abs(host(out["var"])[sub] - var0).max() <= 1e-6 * th[2] ** 2
+    assert np.abs(Sinv_h @ Sh - np.eye(N)).max() < 1e-5
