@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--config", default="c3", help="golden design to fit (c3 = Ackley-shaped N=2048, D=20)")
     ap.add_argument("--candidates", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the RFF / line-acquisition side measurements")
     args = ap.parse_args()
 
     import torch
@@ -156,6 +157,44 @@ def main():
     ks_ms, ks_n = eng.profile_read("kstar")
     sc_ms, sc_n = eng.profile_read("score")
 
+    # ---- secondary rows of SURVEY 8d (rank 0 only, outside the timed region) ------------
+    secondary = {}
+    if rank == 0 and not args.no_secondary:
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / reps
+        F = 4096
+        W = eng.dev(np.random.default_rng(3).standard_normal((F, D)) / th[1])
+        b = eng.dev(np.random.default_rng(4).uniform(0, 2 * np.pi, F))
+        om = eng.dev(np.random.default_rng(5).standard_normal(F))
+        eng.profile_reset()
+        t_proj = timed(lambda: eng.rff_project(Xd, W, b, th[2]), 10)
+        pj_ms, pj_n = eng.profile_read("rff_project")
+        t_rs = timed(lambda: eng.rff_score(Xc, W, b, th[2], om, want_score=False), 5)
+        rs_ms, rs_n = eng.profile_read("rff_score")
+        B, G, S = 512, 70, 150
+        rngl = np.random.default_rng(6)
+        al = np.linspace(0.005, 0.995, G)
+        xs = rngl.random((B, D))
+        grid = np.repeat(xs[:, None, :], G, axis=1)
+        dsel = np.arange(B) % D
+        grid[np.arange(B)[:, None], np.arange(G)[None, :], dsel[:, None]] = al[None, :]
+        gridd = eng.dev(grid)
+        z = eng.dev(rngl.standard_normal((S, G)))
+        t_line = timed(lambda: eng.line_acq(post, gridd, z, mustar, jitter=1e-10 * float(th[2]) ** 2), 3)
+        phi_bytes = 8.0 * F * N
+        secondary = {
+            "rff_project": {"F": F, "kernel_ms": pj_ms / max(pj_n, 1), "bytes": phi_bytes,
+                            "achieved_GBs": phi_bytes / (pj_ms / max(pj_n, 1) * 1e-3) / 1e9, "peak_GBs": PEAK_HBM_GBS},
+            "rff_score_evals_per_s": M / t_rs, "rff_score_kernel_ms": rs_ms / max(rs_n, 1),
+            "line_acq": {"lines": B, "grid": G, "draws": S, "ms": t_line * 1e3, "lines_per_s": B / t_line},
+        }
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * M * args.steps / elapsed
@@ -192,8 +231,17 @@ def main():
                                 "peak_GBs": PEAK_HBM_GBS,
                                 "frac": gram_bytes / (gram_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if gram_avg_ms else None},
             },
+            "secondary": secondary,
             "best": {"value": best[0], "index": best[1]},
         }
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hot_kernels_v3.json")
+        if os.path.exists(pmc):   # fabric-side bytes per launch from the committed rocprofv3 --pmc passes (same command)
+            try:
+                d = json.load(open(pmc))["quadform"]["derived"]
+                line["roofline"]["traffic"] = d["fabric_read_bytes(FETCH_SIZE KB x1024 x2 gfx950 correction)"] + d["write_bytes"]
+                line["roofline"]["traffic_source"] = "profiles/r01_pmc_hot_kernels_v3.json (FETCH_SIZE x2 + WRITE_SIZE)"
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g, 2048)
         print(json.dumps(line))

@@ -17,7 +17,7 @@ namespace {
 constexpr int TS = 64;
 constexpr double INV_SQRT_4PI = 0.28209479177387814347;
 
-__device__ __forceinline__ void stage_T(const double* __restrict__ X, int n, int D, int r0, double* __restrict__ dstT) {
+[[maybe_unused]] __device__ __forceinline__ void stage_T(const double* __restrict__ X, int n, int D, int r0, double* __restrict__ dstT) {
   for (int e = threadIdx.x; e < TS * D; e += blockDim.x) {
     const int r = e / D, d = e - r * D;
     const int gr = r0 + r;
@@ -25,52 +25,79 @@ __device__ __forceinline__ void stage_T(const double* __restrict__ X, int n, int
   }
 }
 
+// cos(x) for |x| < 1.6e6 by a three-constant Cody-Waite reduction to [-pi/4, pi/4] and the fdlibm
+// minimax kernels (about 35 fp64 instructions, <= 1 ulp); larger arguments take the library path.
+// The RFF phases w.x + b are O(sqrt(D)/l) (tens), far inside the fast range.
+__device__ __forceinline__ double rff_cos(double x) {
+  const double ax = fabs(x);
+  if (!(ax < 1.6e6)) return cos(x);
+  const double kf = rint(ax * 6.36619772367581382433e-01);
+  double r = fma(-kf, 1.57079632673412561417e+00, ax);
+  r = fma(-kf, 6.07710050630396597660e-11, r);
+  r = fma(-kf, 2.02226624871116645580e-21, r);
+  r = fma(-kf, 8.47842766036889956997e-32, r);
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                    2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03),
+                    -1.66666666666666324348e-01);
+  const double sn = fma(z * r, ps, r);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                    -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03),
+                    4.16666666666666019037e-02);
+  const double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = ((int)kf) & 3;            // cos(r + q pi/2)
+  const double v = (q & 1) ? sn : cs;
+  return (q == 1 || q == 2) ? -v : v;
+}
+
+// Phi tile [64 features x 64 points] with the phase w_f.x_n + b_f on the fp64 matrix cores:
+//   a_f = ( w_f , b_f , 0.. )   b_n = ( x_n , 1 , 0.. )   (depth DP + 4, compile time)
+// wave w owns feature rows 16w..16w+15; every store instruction writes four full 128-byte lines.
+template <int DP>
 __global__ __launch_bounds__(256) void rff_project_kernel(const double* __restrict__ X, int N, int D,
                                                           const double* __restrict__ W, int F,
                                                           const double* __restrict__ b, double scale,
                                                           double* __restrict__ Phi) {
-  extern __shared__ double smem[];
-  double* WT = smem;                    // [D][64] features
-  double* XT = smem + (size_t)D * TS;   // [D][64] data rows
+  constexpr int KA = DP + 4, LD = KA + 2, Q = DP / 4;
+  __shared__ __attribute__((aligned(16))) double Wa[TS * LD];
+  __shared__ __attribute__((aligned(16))) double Xb[TS * LD];
   const int f0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
-  stage_T(W, F, D, f0, WT);
-  stage_T(X, N, D, n0, XT);
-  __syncthreads();
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  double s[4][4];
+  {
+    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) s[a][c] = 0.0;
-  for (int d = 0; d < D; ++d) {
-    double wa[4], xb[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) wa[a] = WT[d * TS + ty * 4 + a];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) xb[c] = XT[d * TS + tx * 4 + c];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) s[a][c] += wa[a] * xb[c];
+    for (int k = 0; k < Q; ++k) {
+      const int d = part * Q + k;
+      Wa[r * LD + d] = (d < D && f0 + r < F) ? W[(size_t)(f0 + r) * D + d] : 0.0;
+      Xb[r * LD + d] = (d < D && n0 + r < N) ? X[(size_t)(n0 + r) * D + d] : 0.0;
+    }
+    Wa[r * LD + DP + part] = (part == 0 && f0 + r < F) ? b[f0 + r] : 0.0;
+    Xb[r * LD + DP + part] = (part == 0) ? 1.0 : 0.0;
   }
-  const bool vec_ok = ((N & 1) == 0) && ((reinterpret_cast<uintptr_t>(Phi) & 15) == 0);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  double4_t acc[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int f = f0 + ty * 4 + a;
+  for (int j = 0; j < 4; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
+  double af[KA / 4], bf[4][KA / 4];
+#pragma unroll
+  for (int kk = 0; kk < KA / 4; ++kk) af[kk] = Wa[(w * 16 + lr) * LD + kk * 4 + lk];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int kk = 0; kk < KA / 4; ++kk) bf[j][kk] = Xb[(j * 16 + lr) * LD + kk * 4 + lk];
+#pragma unroll
+  for (int kk = 0; kk < KA / 4; ++kk)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[j][kk], acc[j], 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = f0 + w * 16 + lk + 4 * r;
     if (f >= F) continue;
-    const double bf = b[f];
-    double v[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = scale * cos(s[a][c] + bf);
-    const int n = n0 + tx * 4;
-    double* dst = Phi + (size_t)f * N + n;
-    if (vec_ok && n + 3 < N) {
-      *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
-      *reinterpret_cast<double2*>(dst + 2) = make_double2(v[2], v[3]);
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (n + c < N) dst[c] = v[c];
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + j * 16 + lr;
+      if (n < N) Phi[(size_t)f * N + n] = scale * rff_cos(acc[j][r]);
     }
   }
 }
@@ -121,8 +148,8 @@ __global__ __launch_bounds__(RS_THREADS) void rff_score_kernel(const double* __r
         s1 += w * xb[d];
       }
       const double om = s_om[r];
-      a0 += om * cos(s0);
-      a1 += om * cos(s1);
+      a0 += om * rff_cos(s0);
+      a1 += om * rff_cos(s1);
     }
   }
   if (c0 < M) part[(size_t)blockIdx.y * M + c0] = scale * a0;
@@ -227,10 +254,21 @@ int ppbo_rff_project(ppbo_ctx* ctx, const double* d_X, int N, int D, const doubl
   PPBO_REQUIRE(ctx, d_X && d_W && d_b && d_Phi, "null pointer");
   PPBO_REQUIRE(ctx, N > 0 && D > 0 && D <= 256 && F > 0, "sizes");
   const double scale = std::sqrt(2.0 * sigma_f * sigma_f / (double)F);
+  PPBO_REQUIRE(ctx, D <= 64, "D<=64");
   dim3 grid((N + TS - 1) / TS, (F + TS - 1) / TS);
-  const size_t lds = (size_t)2 * D * TS * sizeof(double);
-  PpboProfScope pf(ctx, ppbo_ctx::PF_RFF_PROJECT, (hipStream_t)stream);
-  rff_project_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(d_X, N, D, d_W, F, d_b, scale, d_Phi);
+  hipStream_t s = (hipStream_t)stream;
+  PpboProfScope pf(ctx, ppbo_ctx::PF_RFF_PROJECT, s);
+#define RP_LAUNCH(DPV) rff_project_kernel<DPV><<<grid, 256, 0, s>>>(d_X, N, D, d_W, F, d_b, scale, d_Phi)
+  if (D <= 4) RP_LAUNCH(4);
+  else if (D <= 8) RP_LAUNCH(8);
+  else if (D <= 12) RP_LAUNCH(12);
+  else if (D <= 16) RP_LAUNCH(16);
+  else if (D <= 20) RP_LAUNCH(20);
+  else if (D <= 24) RP_LAUNCH(24);
+  else if (D <= 32) RP_LAUNCH(32);
+  else if (D <= 48) RP_LAUNCH(48);
+  else RP_LAUNCH(64);
+#undef RP_LAUNCH
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
