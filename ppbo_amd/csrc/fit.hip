@@ -369,6 +369,8 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
   int it = 0, nchol = 0;
   bool h_at_zero = false;  // H buffer currently holds the unfactorized lam=0 matrix
 
+  if (!std::isfinite(pt[cur].gn2) || !std::isfinite(pt[cur].fSf))
+    return ppbo_set_error(ctx, -3, "non-finite objective at the start vector");
   while (it < maxiter && std::sqrt(pt[cur].gn2) >= gtol) {
     ++it;
     Vecs& C = pt[cur];
@@ -429,6 +431,9 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
       pn = std::sqrt(W.hsc[0]);
       gtp = W.hsc[1];
       const double qn2 = W.hsc[2];
+      if (!std::isfinite(pn) || !std::isfinite(gtp) || !std::isfinite(qn2))
+        return ppbo_set_error(ctx, -3, "non-finite trust-region step (|p|^2=%g g.p=%g |q|^2=%g) at iteration %d", W.hsc[0],
+                              gtp, qn2, it);
       have_step = true;
       lam_used = lam;
       if (pn <= radius && lam == 0.0) { boundary = false; break; }

