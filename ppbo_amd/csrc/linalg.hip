@@ -72,10 +72,13 @@ __global__ __launch_bounds__(64) void potf2_wave_kernel(double* __restrict__ A, 
 __global__ __launch_bounds__(128) void trsm_panel_kernel(double* __restrict__ A, int lda, int N, int k0,
                                                          const int* __restrict__ info) {
   __shared__ __attribute__((aligned(16))) double Ls[NB * NB];
+  __shared__ double Ds[NB];   // reciprocal pivots: the per-column divide becomes a multiply
   if (*info != 0) return;
   for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
     const int r = e / NB, c = e - r * NB;
-    Ls[e] = (c <= r) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;
+    const double v = (c <= r) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;
+    Ls[e] = v;
+    if (r == c) Ds[r] = 1.0 / v;
   }
   __syncthreads();
   const int i = k0 + NB + blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,8 +92,8 @@ __global__ __launch_bounds__(128) void trsm_panel_kernel(double* __restrict__ A,
     double v = x[c];
 #pragma unroll
     for (int k = 0; k < c; ++k) v -= x[k] * Ls[c * NB + k];
-    x[c] = v / Ls[c * NB + c];
-    __builtin_amdgcn_sched_barrier(0);
+    x[c] = v * Ds[c];
+    if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the hoisting of LDS reads (register pressure)
   }
 #pragma unroll
   for (int c = 0; c < NB; ++c) row[c] = x[c];
