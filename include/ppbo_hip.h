@@ -185,6 +185,20 @@ int ppbo_dgemm(ppbo_ctx* ctx, int transA, int transB, int M, int N, int K, doubl
                const double* d_A, int lda, const double* d_B, int ldb, double beta,
                double* d_C, int ldc, void* stream);
 
+/* ---- a-9: the determinant term of the Laplace evidence ---------------------------------
+ * ppbo_lu_slogdet replaces  P,L,U = scipy.linalg.lu(M); slogdet(P), slogdet(L), slogdet(U)
+ * (src/gp_model.py:303-310): LU with partial pivoting (LAPACK pivot rule) IN PLACE on d_A;
+ * returns *h_u_sign = prod sign(u_ii) and *h_u_logdet = sum log|u_ii|.  P and L contribute
+ * sign*0, so the reference's sum of sign*logdet is exactly (*h_u_sign) * (*h_u_logdet).
+ * *h_info = k>0 if u_kk == 0.
+ * ppbo_laplace_logdet forms M = I + Sigma*Lambda (src/gp_model.py:301-302, plus sign as in the
+ * reference) from the star-form Lambda and calls ppbo_lu_slogdet on it. */
+int ppbo_lu_slogdet(ppbo_ctx* ctx, double* d_A, int N, int lda, double* h_u_sign, double* h_u_logdet,
+                    int* h_info, void* stream);
+int ppbo_laplace_logdet(ppbo_ctx* ctx, const double* d_Sigma, const double* d_lam_diag,
+                        const double* d_lam_off, int N, int m, double* h_u_sign, double* h_u_logdet,
+                        int* h_info, void* stream);
+
 /* y = op(A) x for a square fp64 matrix; lower != 0 reads only the lower triangle (A is then
  * treated as lower-triangular).  Used for alpha = Sigma^-1 f_MAP (src/gp_model.py:445) and
  * prior draws L z (src/gp_model.py:374). */

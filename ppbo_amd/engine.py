@@ -168,6 +168,23 @@ class Engine:
         self._check(rc, "ppbo_dgemm")
         return Cc
 
+    def lu_slogdet_(self, A):
+        """LU with partial pivoting in place; returns (prod sign(u_ii), sum log|u_ii|)."""
+        N = A.shape[0]
+        sg, ld, info = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+        rc = self.lib.ppbo_lu_slogdet(self.ctx, _ptr(A), N, A.stride(0), C.byref(sg), C.byref(ld), C.byref(info),
+                                      self._stream())
+        self._check(rc, "ppbo_lu_slogdet")
+        return sg.value, ld.value, info.value
+
+    def laplace_logdet(self, Sigma, lam_diag, lam_off, m):
+        N = Sigma.shape[0]
+        sg, ld, info = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+        rc = self.lib.ppbo_laplace_logdet(self.ctx, _ptr(Sigma), _ptr(lam_diag), _ptr(lam_off), N, m, C.byref(sg),
+                                          C.byref(ld), C.byref(info), self._stream())
+        self._check(rc, "ppbo_laplace_logdet")
+        return sg.value, ld.value, info.value
+
     def dgemv(self, A, x, trans=False, lower=False):
         A, x = self.dev(A), self.dev(x).reshape(-1)
         N = A.shape[0]

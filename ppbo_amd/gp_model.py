@@ -209,13 +209,60 @@ class GPModel:
 
     # ------------------------------------------------------------------ evidence / hyper-parameters
     def evidence(self, theta, f_initial):
-        raise NotImplementedError(
-            "evidence() (gp_model.py:278-319) needs a signed log-determinant of the indefinite matrix "
-            "I + Sigma*Lambda; the device library only factors SPD matrices so far (DESIGN.md, next rows). "
-            "There is deliberately no CPU fallback.")
+        """Laplace log-marginal likelihood + log-prior (gp_model.py:278-319) on the device.
+        As in the reference, f_initial is IGNORED and redrawn from N(0, self.Sigma) (:294), the matrix is
+        I + Sigma_theta*Lambda_MAP (plus sign, :302) and the determinant term is the sum of sign*logdet over the
+        LU factors (:307-310), i.e. sign(prod diag U) * sum log|diag U| with LAPACK's pivoting."""
+        import scipy.stats
+        theta = [float(t) for t in theta]
+        if self.verbose:
+            print("---------- Iter results ----------------")
+        Sig = self.eng.gram(self._dX, theta, self.kernel.__name__, self.COVARIANCE_SHRINKAGE)
+        Sinv = self.eng.pd_inverse(Sig)
+        f0 = self._draw_prior()
+        fm, st = self.eng.fit_fmap(Sinv, f0, self.m, theta[0], gtol=1e-4, maxiter=500)
+        _, _, ld, lo = self.eng.laplace_terms(fm, self.m, theta[0])
+        sgn, logdet, _ = self.eng.laplace_logdet(Sig, ld, lo, self.m)
+        log_evidence = st["T"] - 0.5 * sgn * logdet
+        lp = (np.log(scipy.stats.lognorm.pdf(theta[0], s=1, scale=np.exp(1)))
+              + np.log(scipy.stats.lognorm.pdf(theta[1], s=0.5, scale=np.exp(-1.4)))
+              + np.log(scipy.stats.lognorm.pdf(theta[2], s=0.5, scale=np.exp(1.7))))
+        value = log_evidence + lp
+        if self.verbose:
+            print("(scaled) Log-evidence: " + str(log_evidence))
+            print("Hyper-parameters: " + str(theta))
+        if np.isnan(value) or not np.isfinite(value):
+            if self.verbose:
+                print("Nan log-evidence!")
+            return -500
+        if self.verbose:
+            print("(scaled) Log-evidence + Log-prior: " + str(value))
+        return float(value)
 
     def optimize_theta(self):
-        raise NotImplementedError("optimize_theta() (gp_model.py:391-413) builds on evidence(); not on the device yet")
+        """Evidence maximisation over (l, sigma_f) with sigma fixed to 1 (gp_model.py:391-413).  The reference
+        drives GPyOpt's Bayesian optimisation (20 initial + 40 iterations = 60 evidence fits); GPyOpt is replaced
+        by the same budget of device evidence fits: 20 uniform draws over the reference's box, then 40 shrinking
+        Gaussian perturbations of the incumbent."""
+        if self.verbose:
+            print("Hyperparameter optimization begins...")
+        start = time.time()
+        lo, hi = np.array([0.01, 0.1]), np.array([2.0, 15.0])
+        best_v, best_t = -np.inf, None
+        for k in range(60):
+            if k < 20 or best_t is None:
+                cand = lo + np.random.uniform(size=2) * (hi - lo)
+            else:
+                width = 0.25 * (hi - lo) * (0.93 ** (k - 20))
+                cand = np.clip(best_t + width * np.random.standard_normal(2), lo, hi)
+            v = self.evidence([1.0, cand[0], cand[1]], self.fMAP)
+            if v > best_v:
+                best_v, best_t = v, cand
+        if self.verbose:
+            print("Optimization of hyperparameters took " + str(time.time() - start) + " seconds.")
+        self.theta = [1.0, float(best_t[0]), float(best_t[1])]
+        if self.verbose:
+            print("The optimized theta is " + str(self.theta))
 
     # ------------------------------------------------------------------ f_MAP
     def _draw_prior(self):

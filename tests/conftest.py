@@ -25,7 +25,8 @@ def load_golden(name):
 def golden_names(pred=lambda n: True):
     if not os.path.isdir(GOLDEN):
         return []
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and pred(f[:-4]))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN)
+                  if f.endswith(".npz") and not f.startswith("_") and pred(f[:-4]))
 
 
 @pytest.fixture(scope="session")

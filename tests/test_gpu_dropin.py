@@ -189,3 +189,20 @@ def test_hsampler_surface(golden, name):
         assert np.abs(hs.cov_diag - g["rff_cov_diag"]).max() <= 1e-4 * np.abs(g["rff_cov_diag"]).max()
         xs = hs.sample_xstar()
         assert xs.shape == (gp.D,) and np.all((xs >= 0) & (xs <= 1))
+
+
+def test_optimize_theta_improves_evidence(golden):
+    """optimize_theta (gp_model.py:391-413): 60 device evidence fits; sigma stays 1, (l, sigma_f) inside the
+    reference's box, and the returned theta scores at least as well as the box centre."""
+    g = golden("smoke")
+    gp, st = _model(g)
+    gp.set_theta(); gp.update_Sigma(gp.theta); gp.update_Sigma_inv(gp.theta)
+    gp.fMAP = g["fMAP"].copy()
+    np.random.seed(4)
+    gp.optimize_theta()
+    assert gp.theta[0] == 1.0 and 0.01 <= gp.theta[1] <= 2.0 and 0.1 <= gp.theta[2] <= 15.0
+    np.random.seed(5)
+    v_opt = gp.evidence(gp.theta, None)
+    np.random.seed(5)
+    v_mid = gp.evidence([1.0, 1.0, 7.5], None)
+    assert v_opt >= v_mid - 1e-3

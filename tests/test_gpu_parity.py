@@ -382,3 +382,35 @@ def test_c5_size_camphor_properties(eng):
     assert rel(host(out["mu"])[sub], mu0) < 1e-6
     assert np.abs(host(out["var"])[sub] - var0).max() <= 1e-6 * th[2] ** 2
     assert np.abs(Sinv_h @ Sh - np.eye(N)).max() < 1e-5
+
+
+# ---------------------------------------------------------------- a-9: LU / evidence
+@pytest.mark.parametrize("N", [1, 5, 31, 32, 33, 64, 100, 257, 513, 1024])
+def test_lu_slogdet_matches_lapack_pivoting(eng, N):
+    import scipy.linalg
+    rng = np.random.default_rng(N)
+    A = rng.standard_normal((N, N))
+    A[rng.integers(0, N, max(1, N // 3)), :] *= -3.0
+    P, L, U = scipy.linalg.lu(A)
+    sgn_ref = np.prod(np.sign(np.diag(U)))
+    ld_ref = np.sum(np.log(np.abs(np.diag(U))))
+    Ad = eng.dev(A.copy())
+    sgn, ld, info = eng.lu_slogdet_(Ad)
+    assert info == 0
+    assert sgn == sgn_ref                                  # pivot sequence (hence the signs of diag U) as LAPACK
+    assert abs(ld - ld_ref) <= 1e-10 * max(1.0, abs(ld_ref))
+    Uh = np.triu(host(Ad))
+    assert np.abs(np.abs(np.diag(Uh)) - np.abs(np.diag(U))).max() <= 1e-9 * np.abs(np.diag(U)).max()
+
+
+@pytest.mark.parametrize("name", [n for n in ("smoke", "rq") if n in ALL])
+def test_evidence_vs_reference(golden, name):
+    """GPModel.evidence on the device against the reference's values (same start vectors via a patched draw)."""
+    from test_gpu_dropin import _model
+    g = golden(name)
+    gp, st = _model(g)
+    gp.set_theta(); gp.update_Sigma(gp.theta); gp.update_Sigma_inv(gp.theta)
+    for th, f0, v in zip(g["ev_theta"], g["ev_finit"], g["ev_value"]):
+        gp._draw_prior = lambda f0=f0: gp.eng.dev(f0)
+        mine = gp.evidence(list(th), None)
+        assert abs(mine - float(v)) <= 1e-5 * max(1.0, abs(float(v))), (list(th), mine, float(v))

@@ -148,6 +148,20 @@ def augment(name):
     print(f"[{name}] augmented {path}")
 
 
+def design_only(name):
+    """Write just the reference-built design (X, X_obs) so a start vector can be prepared elsewhere."""
+    import gp_model as ref_gp
+    import ppbo_settings as ref_settings
+    gp, _, X_obs = build_design(ref_gp, ref_settings, CONFIGS[name])
+    path = os.path.join(OUT, f"_{name}_design.npz")
+    np.savez_compressed(path, X=np.asarray(gp.X), X_obs=X_obs, theta=np.array(CONFIGS[name]["theta"], dtype=float),
+                        m=gp.m, kernel=CONFIGS[name]["kernel"])
+    print(f"[{name}] wrote {path}")
+
+
+START_VECTOR = None   # optional near-optimal start for the reference's own trust-exact run (N=4096 takes hours cold)
+
+
 def run_config(name):
     import gp_model as ref_gp
     import ppbo_settings as ref_settings
@@ -180,6 +194,10 @@ def run_config(name):
 
     # ---- G3: fMAP with a stored start (patched RNG draw) ------------------
     f_init = np.random.default_rng(2).multivariate_normal(np.zeros(N), Sig, method="cholesky")
+    if START_VECTOR is not None:
+        f_init = np.load(START_VECTOR).astype(np.float64).ravel()
+        assert f_init.shape == (N,)
+        out["f_init_is_warm_start"] = True
     _mvn = np.random.multivariate_normal
     np.random.multivariate_normal = lambda mean, cov, *a, **k: f_init.copy()
     try:
@@ -309,6 +327,13 @@ if __name__ == "__main__":
     if args and args[0] == "--augment":
         for nm in args[1:]:
             augment(nm)
+    elif args and args[0] == "--design-only":
+        for nm in args[1:]:
+            design_only(nm)
+    elif args and args[0] == "--start":
+        START_VECTOR = args[1]
+        for nm in args[2:]:
+            run_config(nm)
     else:
         for nm in (args or ["smoke", "rq", "cam_small", "c2"]):
             run_config(nm)
