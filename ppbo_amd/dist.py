@@ -33,18 +33,17 @@ def combine_best(vals: torch.Tensor, idxs: torch.Tensor):
 
 
 def allgather_argmax(local_val: float, local_global_idx: int, device=None, group=None):
-    """All ranks get the global (value, index).  Index travels as int64, value as float64."""
+    """All ranks get the global (value, index) from ONE all-gather of a 16-byte record per rank.
+    The index travels as a float64 (exact below 2**53)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return float(local_val), int(local_global_idx)
     world = dist.get_world_size(group)
     dev = device if device is not None else torch.device("cpu")
-    rec_v = torch.tensor([float(local_val)], dtype=torch.float64, device=dev)
-    rec_i = torch.tensor([int(local_global_idx)], dtype=torch.int64, device=dev)
-    out_v = torch.empty(world, dtype=torch.float64, device=dev)
-    out_i = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(out_v, rec_v, group=group)
-    dist.all_gather_into_tensor(out_i, rec_i, group=group)
-    return combine_best(out_v.cpu(), out_i.cpu())
+    rec = torch.tensor([float(local_val), float(local_global_idx)], dtype=torch.float64, device=dev)
+    out = torch.empty(2 * world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, rec, group=group)
+    out = out.cpu().view(world, 2)
+    return combine_best(out[:, 0], out[:, 1].to(torch.int64))
 
 
 def sharded_search(engine, post, Xc_shard, shard_offset: int, score, mustar=0.0, group=None):
