@@ -99,6 +99,158 @@ __global__ __launch_bounds__(128) void trsm_panel_kernel(double* __restrict__ A,
   for (int c = 0; c < NB; ++c) row[c] = x[c];
 }
 
+// ---- second-generation panel kernels: blocked by 16 columns so the O(64^3) work runs on the matrix cores
+constexpr int BLD = NB + 2;   // padded LDS row (doubles): conflict-free MFMA fragment reads
+
+// 64x64 diagonal block, four wavefronts.  For each 16-column slab: wave 0 (lane = row) factors the slab
+// with v_readlane-moved multipliers -- 120 rank-1 column updates instead of 2016 -- which also solves the
+// rows below the slab's diagonal; then all waves apply the slab to the trailing columns of the block with
+// v_mfma_f64_16x16x4_f64 (tile -= L_slab(rows) L_slab(cols)^T, operands and accumulators in LDS).
+__global__ __launch_bounds__(256) void potf2_block_kernel(double* __restrict__ A, int lda, int k0, int kb,
+                                                          int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double Ab[NB * BLD];
+  __shared__ int s_fail;
+  if (*info != 0) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int e = t; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e - r * NB;
+    Ab[r * BLD + c] = (r < kb && c < kb && c <= r) ? A[(size_t)(k0 + r) * lda + k0 + c] : ((r == c) ? 1.0 : 0.0);
+  }
+  if (t == 0) s_fail = 0;
+  __syncthreads();
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int c0 = 16 * s;
+    if (wave == 0) {
+      double a[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a[j] = Ab[lane * BLD + c0 + j];
+      int fail = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double d = lane_bcast(a[j], c0 + j);
+        if (!(d > 0.0) && fail == 0 && c0 + j < kb) fail = c0 + j + 1;
+        const double rs = rsqrt_refined(d);
+        const double lij = (lane == c0 + j) ? d * rs : a[j] * rs;
+        a[j] = lij;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] -= lij * lane_bcast(lij, c0 + k);
+      }
+      if (lane >= c0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Ab[lane * BLD + c0 + j] = a[j];
+      }
+      if (fail && lane == 0 && s_fail == 0) s_fail = fail;
+    }
+    __syncthreads();
+    if (s_fail) break;
+    // trailing tiles (rb >= cb > s) of the 4x4 tile grid, round-robin over the four waves
+    int tile = 0;
+#pragma unroll
+    for (int cb = 1; cb < 4; ++cb) {
+#pragma unroll
+      for (int rb = 1; rb < 4; ++rb) {
+        if (cb <= s || rb < cb) continue;
+        if ((tile++ & 3) != wave) continue;
+        double4_t acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Ab[(16 * rb + lk + 4 * r) * BLD + 16 * cb + lr];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const double av = -Ab[(16 * rb + lr) * BLD + c0 + kk * 4 + lk];
+          const double bv = Ab[(16 * cb + lr) * BLD + c0 + kk * 4 + lk];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ab[(16 * rb + lk + 4 * r) * BLD + 16 * cb + lr] = acc[r];
+      }
+    }
+    __syncthreads();
+  }
+  if (s_fail) {
+    if (t == 0) *info = k0 + s_fail;
+    return;
+  }
+  for (int e = t; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e - r * NB;
+    if (r < kb && c <= r) A[(size_t)(k0 + r) * lda + k0 + c] = Ab[r * BLD + c];
+  }
+}
+
+// rows i >= k0+64: X = B L_kk^-T by 16-column blocks on the matrix cores.  One wavefront = 16 rows.
+//   X_c = (B_c - sum_{p<c} X_p L_cp^T) inv(L_cc)^T,  c = 0..3
+// inv(L_cc) (four 16x16 triangles) is computed once per workgroup by wave 0 (lane = block*16 + column).
+__global__ __launch_bounds__(256) void trsm_mfma_kernel(double* __restrict__ A, int lda, int N, int k0,
+                                                        const int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double Lk[NB * BLD];        // L_kk
+  __shared__ __attribute__((aligned(16))) double Li[4 * 16 * 18];     // inv(L_cc)[j][k], row stride 18
+  __shared__ __attribute__((aligned(16))) double Xs[4][16 * BLD];     // per wave: solved / staged row tile
+  if (*info != 0) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int e = t; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e - r * NB;
+    Lk[r * BLD + c] = (c <= r) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int b = lane >> 4, c = lane & 15;      // column c of inv(L_bb)
+    double y[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) v -= Lk[(16 * b + r) * BLD + 16 * b + k] * y[k];
+      y[r] = (r >= c) ? v / Lk[(16 * b + r) * BLD + 16 * b + r] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Li[(b * 16 + r) * 18 + c] = y[r];
+  }
+  __syncthreads();
+  const int row0 = k0 + NB + (blockIdx.x * 4 + wave) * 16;
+  if (row0 >= N) return;
+  double* xs = Xs[wave];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gr = row0 + lk + 4 * r;
+      acc[r] = (gr < N) ? A[(size_t)gr * lda + k0 + 16 * c + lr] : 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (p >= c) continue;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const double av = -xs[lr * BLD + 16 * p + kk * 4 + lk];
+        const double bv = Lk[(16 * c + lr) * BLD + 16 * p + kk * 4 + lk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+    }
+    // residual tile -> A-operand orientation through this wave's staging columns 16c..16c+15
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xs[(lk + 4 * r) * BLD + 16 * c + lr] = acc[r];
+    __builtin_amdgcn_wave_barrier();
+    double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const double av = xs[lr * BLD + 16 * c + kk * 4 + lk];
+      const double bv = Li[(c * 16 + lr) * 18 + kk * 4 + lk];       // B[k][j] = inv(L_cc)[j][k]
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xs[(lk + 4 * r) * BLD + 16 * c + lr] = x[r];
+      const int gr = row0 + lk + 4 * r;
+      if (gr < N) A[(size_t)gr * lda + k0 + 16 * c + lr] = x[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // inverse of the 64x64 diagonal blocks of lower-triangular L; lane = column of the inverse.
 // The running column lives in LDS ([r][lane], conflict free); L entries are broadcast reads.
 __global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict__ L, int ldl, int N,
@@ -195,15 +347,23 @@ __global__ void set_int_kernel(int* p, int v) { *p = v; }
 
 }  // namespace
 
+static int potrf_gen() {
+  static int g = -1;
+  if (g < 0) { const char* e = getenv("PPBO_POTRF_GEN"); g = e ? atoi(e) : 2; }
+  return g;
+}
+
 int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hipStream_t s) {
   PpboProfScope pf(ctx, ppbo_ctx::PF_POTRF, s);
   set_int_kernel<<<1, 1, 0, s>>>(d_info, 0);
   for (int k0 = 0; k0 < N; k0 += NB) {
     const int kb = (N - k0 < NB) ? (N - k0) : NB;
-    potf2_wave_kernel<<<1, 64, 0, s>>>(d_A, lda, k0, kb, d_info);
+    if (potrf_gen() >= 2) potf2_block_kernel<<<1, 256, 0, s>>>(d_A, lda, k0, kb, d_info);
+    else potf2_wave_kernel<<<1, 64, 0, s>>>(d_A, lda, k0, kb, d_info);
     const int rest = N - k0 - NB;
     if (rest > 0) {
-      trsm_panel_kernel<<<(rest + 127) / 128, 128, 0, s>>>(d_A, lda, N, k0, d_info);
+      if (potrf_gen() >= 2) trsm_mfma_kernel<<<(rest + 63) / 64, 256, 0, s>>>(d_A, lda, N, k0, d_info);
+      else trsm_panel_kernel<<<(rest + 127) / 128, 128, 0, s>>>(d_A, lda, N, k0, d_info);
       GemmArgs g{};
       g.A = d_A + (size_t)(k0 + NB) * lda + k0; g.lda = lda;
       g.B = g.A; g.ldb = lda;
