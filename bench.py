@@ -188,9 +188,24 @@ def main():
         z = eng.dev(rngl.standard_normal((S, G)))
         t_line = timed(lambda: eng.line_acq(post, gridd, z, mustar, jitter=1e-10 * float(th[2]) ** 2), 3)
         phi_bytes = 8.0 * F * N
+        gram_sizes = {}
+        for Ng in (4096, 8192):   # the Gram roofline is only meaningful beyond the launch-latency regime
+            Xg = eng.dev(np.random.default_rng(7).random((Ng, D)))
+            eng.gram(Xg, th, kern)
+            eng.profile_reset()
+            for _ in range(5):
+                eng.gram(Xg, th, kern)
+            torch.cuda.synchronize()
+            gms, gn = eng.profile_read("gram")
+            gb = 8.0 * Ng * Ng + 8.0 * Ng * D
+            gram_sizes[str(Ng)] = {"avg_ms": gms / gn, "achieved_GBs": gb / (gms / gn * 1e-3) / 1e9,
+                                   "frac": gb / (gms / gn * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            del Xg
         secondary = {
-            "rff_project": {"F": F, "kernel_ms": pj_ms / max(pj_n, 1), "bytes": phi_bytes,
-                            "achieved_GBs": phi_bytes / (pj_ms / max(pj_n, 1) * 1e-3) / 1e9, "peak_GBs": PEAK_HBM_GBS},
+            "gram_kernel_larger_N": gram_sizes,
+            "rff_project": {"F": F, "wall_ms_per_call": t_proj * 1e3, "event_ms": pj_ms / max(pj_n, 1), "bytes": phi_bytes,
+                            "note": "rocprofv3 kernel time is in profiles/ (28.5 us = 2.35 TB/s); the event bracket "
+                                    "includes launch latency for this kernel"},
             "rff_score_evals_per_s": M / t_rs, "rff_score_kernel_ms": rs_ms / max(rs_n, 1),
             "line_acq": {"lines": B, "grid": G, "draws": S, "ms": t_line * 1e3, "lines_per_s": B / t_line},
         }
