@@ -7,12 +7,12 @@
 namespace {
 
 using namespace gemm64;
-using GCBig = Cfg<2, 2, 4, 4>;     // 128 x 128 tile, 4 wavefronts of 64 x 64: large, compute-bound products
+using GCBig = Cfg<4, 2, 2, 4>;     // 128 x 128 tile, 8 wavefronts of 32 x 64 (4 waves/SIMD): large products
 using GCSmall = Cfg<2, 2, 2, 2>;   // 64 x 64 tile, 4 wavefronts of 32 x 32: short-K panel updates, where the
                                    // grid must put >= 2 wavefronts on every SIMD to reach the 64-cycle MFMA rate
 
 template <class GC, int ALAY, int BLAY>
-__global__ __launch_bounds__(256, 2) void dgemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GC::NT, (GC::NT == 512) ? 4 : 2) void dgemm_kernel(GemmArgs g) {
   constexpr int BM = GC::BM, BN = GC::BN;
   if (g.batch > 1) {
     g.A += (size_t)blockIdx.y * g.strideA;
@@ -68,10 +68,10 @@ int launch_cfg(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, hipStre
     attr_done = true;
   }
   const dim3 grid(ntm * ntn, g.batch > 1 ? g.batch : 1);
-  if (!transA && !transB) dgemm_kernel<GC, KC, RC><<<grid, 256, lds, s>>>(g);
-  else if (!transA && transB) dgemm_kernel<GC, KC, KC><<<grid, 256, lds, s>>>(g);
-  else if (transA && !transB) dgemm_kernel<GC, RC, RC><<<grid, 256, lds, s>>>(g);
-  else dgemm_kernel<GC, RC, KC><<<grid, 256, lds, s>>>(g);
+  if (!transA && !transB) dgemm_kernel<GC, KC, RC><<<grid, GC::NT, lds, s>>>(g);
+  else if (!transA && transB) dgemm_kernel<GC, KC, KC><<<grid, GC::NT, lds, s>>>(g);
+  else if (transA && !transB) dgemm_kernel<GC, RC, RC><<<grid, GC::NT, lds, s>>>(g);
+  else dgemm_kernel<GC, RC, KC><<<grid, GC::NT, lds, s>>>(g);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
