@@ -173,6 +173,7 @@ using QF1 = Cfg<2, 4, 4, 2>;   // 8 waves of 64x32, 2 WG/CU -> 4 waves/SIMD
 using QF2 = Cfg<4, 2, 2, 4>;   // 8 waves of 32x64
 using QF3 = Cfg<4, 4, 2, 2>;   // 16 waves of 32x32, 1 WG/CU -> 4 waves/SIMD
 using QF4 = Cfg<4, 4, 2, 2>;   // same tile, 2 WG/CU -> 8 waves/SIMD (<= 64 VGPRs)
+using QF5 = Cfg<8, 2, 2, 4>;   // 256 x 128 tile, 16 waves of 32x64, 1 WG/CU: K* re-read once per 256 G rows
 
 template <class C, int MINW>
 int launch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, int ldk, int Mc, int mblk,
@@ -205,7 +206,7 @@ int quadform_variant() {
   if (v < 0) {
     const char* e = getenv("PPBO_QF_VARIANT");
     v = e ? atoi(e) : 2;   // measured best on MI355X: 8 waves of 32x64, 4 waves/SIMD
-    if (v < 0 || v > 4) v = 0;
+    if (v < 0 || v > 5) v = 0;
   }
   return v;
 }
@@ -217,6 +218,7 @@ int dispatch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, i
     case 2: return launch_quadform<QF2, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
     case 3: return launch_quadform<QF3, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
     case 4: return launch_quadform<QF4, 8>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
+    case 5: return launch_quadform<QF5, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
     default: return launch_quadform<QF0, 2>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
   }
 }
@@ -395,7 +397,8 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
   const int N = model->N, mblk = model->m + 1, n_q = N / mblk;
   const int64_t chunk_cap = 65536;
   const int64_t n_chunks = (M + chunk_cap - 1) / chunk_cap;
-  const int ntm = (N + 127) / 128;   // every quadform variant uses 128-row tiles
+  const int qf_bm = (quadform_variant() == 5) ? 256 : 128;
+  const int ntm = (N + qf_bm - 1) / qf_bm;   // slabs = row tiles of the shipped quadform shape
 
   // workspaces sized for the largest chunk
   const int Mc_max = (int)(M < chunk_cap ? M : chunk_cap);

@@ -292,9 +292,9 @@ class GPModel:
             if st["T"] > best_T:
                 best_T, best, self.fit_stats = st["T"], fm, st
         self.fMAP = best.cpu().numpy()
-        self._post = None
+        # like the reference, the previous Lambda_MAP / posterior covariance stay in place until
+        # update_model recomputes them (and survive a failed recomputation, gp_model.py:115-120)
         self._refresh_mean_state(best)
-        self._invalidate("Lambda_MAP", "P", "Pinv")
 
     def _refresh_mean_state(self, fmap_dev):
         from .engine import Posterior

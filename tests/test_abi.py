@@ -49,3 +49,19 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# the oracle", ""), \
                     f"{f} mentions the oracle: the product path must not depend on it"
+
+
+def test_ctx_create_without_gpu_returns_an_error_code():
+    """No GPU in the build container: the C entry point must report it as a status code, not crash."""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ppbo_amd import _lib
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    rc = lib.ppbo_ctx_create(0, C.byref(ctx))
+    assert rc != 0 and not ctx.value
+    assert lib.ppbo_ctx_destroy(None) == 0
+    buf = C.create_string_buffer(16)
+    assert lib.ppbo_last_error(None, buf, 16) != 0

@@ -414,3 +414,59 @@ def test_evidence_vs_reference(golden, name):
         gp._draw_prior = lambda f0=f0: gp.eng.dev(f0)
         mine = gp.evidence(list(th), None)
         assert abs(mine - float(v)) <= 1e-5 * max(1.0, abs(float(v))), (list(th), mine, float(v))
+
+
+# ---------------------------------------------------------------- error conventions of the C-ABI
+def test_error_codes_and_messages(eng, golden):
+    import ctypes as C
+    from ppbo_amd.engine import NotPositiveDefinite
+    g = golden("smoke")
+    X = eng.dev(g["X"])
+    with pytest.raises(RuntimeError, match="camphor kernel needs D == 6"):
+        eng.gram(X, g["theta"], "camphor_copper_kernel")
+    with pytest.raises(RuntimeError, match="n_q\\*\\(m\\+1\\)"):
+        eng.laplace_terms(np.zeros(65), 31, 0.1)
+    S = eng.gram(X, g["theta"])
+    Sinv = eng.pd_inverse(S)
+    # every pseudo-observation sqrt(2) sigma above its observation maximises Lambda's weights:
+    # Sigma^-1 - Lambda is then indefinite (min eigenvalue -1.06 here); the reference prints and keeps the
+    # old posterior (gp_model.py:118-120)
+    f_bad = np.where(np.arange(X.shape[0]) % (int(g["m"]) + 1) != 0, 1.414 * float(g["theta"][0]), 0.0)
+    with pytest.raises(NotPositiveDefinite):
+        eng.posterior(X, g["theta"], "SE_kernel", Sinv, f_bad, int(g["m"]))
+    # null pointers / bad sizes are status codes, never crashes
+    assert eng.lib.ppbo_gram(eng.ctx, 0, None, 4, 2, (C.c_double * 3)(0.1, 0.3, 0.5), 1e-6, None, None) < 0
+    assert eng.lib.ppbo_predict(eng.ctx, None, None, 10, 0, 0.0, None, None, None, None, None, None) < 0
+    buf = C.create_string_buffer(256)
+    eng.lib.ppbo_last_error(eng.ctx, buf, 256)
+    assert b"invalid argument" in buf.value
+    # per-kernel event timing hooks
+    eng.profile(True)
+    eng.gram(X, g["theta"])
+    ms, n = eng.profile_read("gram")
+    assert n == 1 and ms > 0
+    eng.profile(False)
+    with pytest.raises(RuntimeError, match="unknown profile name"):
+        eng.profile_read("nope")
+
+
+def test_dropin_posterior_not_psd_prints_and_continues(golden, capsys):
+    from test_gpu_dropin import _model
+    g = golden("smoke")
+    gp, st = _model(g)
+    gp.turn_initialization_off()
+    np.random.seed(2)
+    gp.update_model()
+    old_post = gp._post
+    assert old_post is not None
+    # force an indefinite posterior precision on the next update
+    real_fit = gp.eng.fit_fmap
+    f_bad = np.where(np.arange(gp.N) % (gp.m + 1) != 0, 1.414 * float(gp.theta[0]), 0.0)
+    gp.eng.fit_fmap = lambda *a, **k: (gp.eng.dev(f_bad),
+                                       dict(iterations=0, n_cholesky=0, converged=False, T=-1.0, gradnorm=1.0))
+    try:
+        gp.update_model()
+    finally:
+        gp.eng.fit_fmap = real_fit
+    assert "Posterior covariance matrix is not PSD" in capsys.readouterr().out
+    assert gp._post is old_post
