@@ -218,8 +218,9 @@ def main():
         # algorithmic flops of the variance contraction per launch: 2 M N^2 (dense A);
         # executed: the block-triangular G form does M * sum_tiles 2*128*kend(tile) flops
         algo_flops = 2.0 * M * N * N
-        tiles = (N + 127) // 128
-        exec_flops = sum(2.0 * 128 * M * min(N, -(-((t + 1) * 128) // mblk) * mblk) for t in range(tiles))
+        # executed: each wavefront owns 32 rows of a 128-row tile and stops at the end of their last star block
+        wrows = 32
+        exec_flops = sum(2.0 * wrows * M * min(N, -(-((b + 1) * wrows) // mblk) * mblk) for b in range(-(-N // wrows)))
         achieved = algo_flops / (qf_avg_ms * 1e-3) / 1e12
         executed = exec_flops / (qf_avg_ms * 1e-3) / 1e12
         gram_bytes = 8.0 * N * N + 8.0 * N * D

@@ -97,10 +97,12 @@ __device__ __forceinline__ int frag_off(int r, int k) {
   return (LAY == KC) ? r * KC_LD + k : k * (ROWS + 16) + r;
 }
 
+// k_wave_end: this wavefront's rows of A are zero for k >= k_wave_end (block-triangular A): its MFMAs beyond
+// that depth are skipped (wave-uniform branch); the other workgroup on the CU uses the freed matrix-core slots.
 template <class C, int ALAY, int BLAY, bool FAST>
 __device__ __forceinline__ void mainloop_impl(const double* __restrict__ A, int lda, const double* __restrict__ B,
                                               int ldb, int M, int N, int m0, int n0, int kbeg, int kend,
-                                              double4_t acc[C::TM][C::TN]) {
+                                              double4_t acc[C::TM][C::TN], int k_wave_end) {
   constexpr int BUF = C::IMG_A + C::IMG_B;   // buffer b: A image at b*BUF, B image at b*BUF + IMG_A
   constexpr int PA = C::BM * 8 / C::NT, PB = C::BN * 8 / C::NT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -138,39 +140,49 @@ __device__ __forceinline__ void mainloop_impl(const double* __restrict__ A, int 
     // the MFMAs of k-step kk issue
     const double* la = lds_dyn + cur + a_lane;
     const double* lb = lds_dyn + cur + b_lane;
-    double a0[C::TM], b0[C::TN], a1[C::TM], b1[C::TN];
+    const int kt0 = kbeg + kt * BK;
+    if (kt0 < k_wave_end) {
+      const bool full = (kt0 + BK <= k_wave_end);
+      double a0[C::TM], b0[C::TN], a1[C::TM], b1[C::TN];
 #pragma unroll
-    for (int i = 0; i < C::TM; ++i) a0[i] = la[i * A_I];
+      for (int i = 0; i < C::TM; ++i) a0[i] = la[i * A_I];
 #pragma unroll
-    for (int j = 0; j < C::TN; ++j) b0[j] = lb[j * B_J];
+      for (int j = 0; j < C::TN; ++j) b0[j] = lb[j * B_J];
 #pragma unroll
-    for (int i = 0; i < C::TM; ++i) a1[i] = la[A_K + i * A_I];
+      for (int i = 0; i < C::TM; ++i) a1[i] = la[A_K + i * A_I];
 #pragma unroll
-    for (int j = 0; j < C::TN; ++j) b1[j] = lb[B_K + j * B_J];
+      for (int j = 0; j < C::TN; ++j) b1[j] = lb[B_K + j * B_J];
 #pragma unroll
-    for (int i = 0; i < C::TM; ++i)
+      for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-      for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      if (full || kt0 + 4 < k_wave_end) {
 #pragma unroll
-    for (int i = 0; i < C::TM; ++i) a0[i] = la[2 * A_K + i * A_I];
+        for (int i = 0; i < C::TM; ++i) a0[i] = la[2 * A_K + i * A_I];
 #pragma unroll
-    for (int j = 0; j < C::TN; ++j) b0[j] = lb[2 * B_K + j * B_J];
+        for (int j = 0; j < C::TN; ++j) b0[j] = lb[2 * B_K + j * B_J];
 #pragma unroll
-    for (int i = 0; i < C::TM; ++i)
+        for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-      for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      }
+      if (full || kt0 + 8 < k_wave_end) {
 #pragma unroll
-    for (int i = 0; i < C::TM; ++i) a1[i] = la[3 * A_K + i * A_I];
+        for (int i = 0; i < C::TM; ++i) a1[i] = la[3 * A_K + i * A_I];
 #pragma unroll
-    for (int j = 0; j < C::TN; ++j) b1[j] = lb[3 * B_K + j * B_J];
+        for (int j = 0; j < C::TN; ++j) b1[j] = lb[3 * B_K + j * B_J];
 #pragma unroll
-    for (int i = 0; i < C::TM; ++i)
+        for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-      for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      }
+      if (full || kt0 + 12 < k_wave_end) {
 #pragma unroll
-    for (int i = 0; i < C::TM; ++i)
+        for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-      for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      }
+    }
     // the other buffer was last read in iteration kt-1 (barrier since then): safe to overwrite
 #pragma unroll
     for (int p = 0; p < PA; ++p) store_elem<ALAY, C::BM, C::NT>(BUF - cur, p, ra[p]);
@@ -185,15 +197,15 @@ __device__ __forceinline__ void mainloop_impl(const double* __restrict__ A, int 
 template <class C, int ALAY, int BLAY, bool ALWAYS_FAST = false>
 __device__ __forceinline__ void mainloop(const double* __restrict__ A, int lda, const double* __restrict__ B,
                                          int ldb, int M, int N, int m0, int n0, int kbeg, int kend,
-                                         double4_t acc[C::TM][C::TN]) {
+                                         double4_t acc[C::TM][C::TN], int k_wave_end = 0x7fffffff) {
   if (kend <= kbeg) return;
   if (ALWAYS_FAST) {
-    mainloop_impl<C, ALAY, BLAY, true>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc);
+    mainloop_impl<C, ALAY, BLAY, true>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc, k_wave_end);
     return;
   }
   const bool fast = tile_fast<C::BM>(A, lda, m0, kbeg, kend, M) && tile_fast<C::BN>(B, ldb, n0, kbeg, kend, N);
-  if (fast) mainloop_impl<C, ALAY, BLAY, true>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc);
-  else mainloop_impl<C, ALAY, BLAY, false>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc);
+  if (fast) mainloop_impl<C, ALAY, BLAY, true>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc, k_wave_end);
+  else mainloop_impl<C, ALAY, BLAY, false>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc, k_wave_end);
 }
 
 template <class C>

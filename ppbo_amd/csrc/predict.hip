@@ -142,7 +142,10 @@ __global__ __launch_bounds__(C::NT, MINW) void quadform_kernel(const double* __r
   const int kend = e < N ? e : N;
   double4_t acc[C::TM][C::TN];
   zero_acc<C>(acc);
-  mainloop<C, KC, RC, ALWAYS_FAST>(G, N, Kt, ldk, N, M, m0, n0, 0, kend, acc);
+  // rows of this wavefront end at m0 + (wm+1)*TM*16: G is zero beyond the end of their last star block
+  const int wrow_end = m0 + ((int)(threadIdx.x >> 6) / C::WN + 1) * C::TM * 16;
+  const int wk = ((wrow_end + tri_block - 1) / tri_block) * tri_block;
+  mainloop<C, KC, RC, ALWAYS_FAST>(G, N, Kt, ldk, N, M, m0, n0, 0, kend, acc, wk < kend ? wk : kend);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / C::WN, wn = wave % C::WN;
   double* red = lds_dyn;  // [WM][BN]; mainloop ended with a barrier
