@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""PPBO on Hartmann6 with the drop-in classes (the reference's run_ppbo_loop, ppbo_numerical_main.py:57-127,
+with its hartmann6d setup :174-183): D initial coordinate queries, then PCD / EI-EXT-FAST queries answered by a
+simulated user who picks the best point on the projective line.
+
+    python examples/ppbo_hartmann6.py --queries 30 --strategy PCD
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+A = np.array([[10, 3, 17, 3.5, 1.7, 8], [0.05, 10, 17, 0.1, 8, 14], [3, 3.5, 1.7, 10, 17, 8], [17, 8, 0.05, 10, 0.1, 14]])
+P = 1e-4 * np.array([[1312, 1696, 5569, 124, 8283, 5886], [2329, 4135, 8307, 3736, 1004, 9991],
+                     [2348, 1451, 3522, 2883, 3047, 6650], [4047, 8828, 8732, 5743, 1091, 381]])
+ALPHA = np.array([1.0, 1.2, 3.0, 3.2])
+
+
+def hartmann6(x):
+    x = np.atleast_2d(x)
+    inner = np.einsum("kd,nkd->nk", A, (x[:, None, :] - P[None, :, :]) ** 2)
+    return -(ALPHA[None, :] * np.exp(-inner)).sum(axis=1)       # minimum -3.322 at (0.2017, 0.15, 0.4769, 0.2753, 0.3117, 0.6573)
+
+
+def user(xi, x, lo, hi):
+    from ppbo_amd.misc import alpha_bounds
+    a0, a1 = alpha_bounds(xi, lo, hi)
+    al = np.linspace(a0, a1, 2001)
+    return float(al[np.argmin(hartmann6(al[:, None] * xi[None, :] + x[None, :]))])
+
+
+def run(queries=30, strategy="PCD", m=31, seed=0, verbose=False):
+    from ppbo_amd.acquisition import next_query
+    from ppbo_amd.gp_model import GPModel
+    from ppbo_amd.ppbo_settings import PPBO_settings
+    D = 6
+    bounds = ((0, 1),) * D
+    lo, hi = np.zeros(D), np.ones(D)
+    np.random.seed(seed)
+    st = PPBO_settings(D=D, bounds=bounds, xi_acquisition_function=strategy, m=m, theta_initial=[0.001, 0.26, 0.1],
+                       verbose=False)
+    xis = np.eye(D)
+    xs = np.random.uniform(lo, hi, (D, D))
+    results = np.empty((0, 2 * D + 1))
+    gp = None
+    hist = []
+    t0 = time.time()
+    for i in range(D):
+        if i == D - 1 and gp is not None:
+            gp.turn_initialization_off()
+        xi, x = xis[i].copy(), xs[i].copy()
+        x[xi != 0] = 0
+        a = user(xi, x, lo, hi)
+        results = np.vstack([results, np.concatenate([a * xi + x, xi, [a]])])
+        if gp is None:
+            gp = GPModel(st)
+        gp.update_feedback_processing_object(results)
+        gp.update_data()
+        gp.update_model()
+    gp.turn_initialization_off()
+    for i in range(queries):
+        if i + 1 == queries:
+            gp.set_last_iteration()
+        xi, x = next_query(st, gp, unscale=True)
+        a = user(xi, x, lo, hi)
+        results = np.vstack([results, np.concatenate([a * xi + x, xi, [a]])])
+        gp.update_feedback_processing_object(results)
+        gp.mustar_previous_iteration = gp.mustar
+        gp.update_data()
+        gp.update_model()
+        fx = float(hartmann6(gp.FP.unscale(gp.xstar))[0])
+        hist.append(fx)
+        if verbose:
+            print(f"query {i + 1:3d}  N={gp.N:5d}  f(x*)={fx:+.4f}  fit iters={gp.fit_stats['iterations']:4d} "
+                  f"chol={gp.fit_stats['n_cholesky']:5d}  elapsed {time.time() - t0:6.1f}s")
+    return gp, hist
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--queries", type=int, default=30)
+    ap.add_argument("--strategy", default="PCD")
+    ap.add_argument("--m", type=int, default=31)
+    args = ap.parse_args()
+    gp, hist = run(args.queries, args.strategy, args.m, verbose=True)
+    print("best f(x*) reached:", min(hist), "(global minimum -3.322)")
