@@ -236,6 +236,30 @@ struct Vecs {  // one evaluation point
   double pv;   // p.(v_prev + v_this) when evaluated as a trial point
 };
 
+// p given (device): fn = f + p ; out: [0]=|p|^2 [1]=g.p
+__global__ __launch_bounds__(1024) void restep_kernel(const double* __restrict__ p, const double* __restrict__ g,
+                                                      const double* __restrict__ f, int N, double* __restrict__ fn,
+                                                      double* __restrict__ out) {
+  __shared__ double sh[2][16];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    const double pi = p[i];
+    fn[i] = f[i] + pi;
+    a += pi * pi;
+    b += g[i] * pi;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0.0, sb = 0.0;
+    for (int w = 0; w < 16; ++w) { sa += sh[0][w]; sb += sh[1][w]; }
+    out[0] = sa;
+    out[1] = sb;
+  }
+}
+
 struct FitWork {
   ppbo_ctx* ctx;
   hipStream_t s;
@@ -360,10 +384,12 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
   if (int rc = eval_point(W, pt[cur])) return rc;
 
   double radius = 1.0;
-  const double rmax = 1000.0, eta = 0.15, k_easy = 0.1;
+  const double rmax = 1000.0, eta = 0.15, k_easy = 0.1, k_hard = 0.2;
+  std::vector<double> host_p(N), host_z(N), host_lz(N), host_g(N);
+  bool host_g_valid = false;
   double lam_lb_prev = 0.0;
   double prev_lam = 0.0, prev_radius = 1.0;
-  bool prev_boundary = false;
+  bool prev_boundary = false, prev_failed = false;
   bool shrink = false, h_changed = true;
   double st_mindiag = 0, st_gmax = 0, st_gmin = 0, st_fro = 0, st_inf = 0;
   int it = 0, nchol = 0;
@@ -398,9 +424,15 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
     // off-diagonals, so those bounds are loose).  lam = 0 is still tried first whenever it is not ruled out.
     double warm = 0.0;
     if (prev_lam > 0.0 && prev_boundary) warm = prev_lam * (prev_radius / radius);
-    if (lb > 0.0 && warm > lb && warm < ub) { lam = warm; warm = 0.0; }
-    bool boundary = true, have_step = false;
-    double pn = 0.0, gtp = 0.0, lam_used = 0.0;
+    const bool had_guess = warm > 0.0;
+    double best_pd = INFINITY;   // smallest shift of this subproblem whose factorization succeeded
+    // lam = 0 (interior Newton step) is tried first unless it is ruled out by the Gershgorin bound or the
+    // previous subproblem PROVED indefiniteness by a failed factorization (H changes little between iterates)
+    if ((lb > 0.0 || prev_failed) && warm > lb && warm < ub) { lam = warm; warm = 0.0; }
+    bool any_failed = false;
+    bool boundary = true, have_step = false, used_hard = false;
+    double pn = 0.0, gtp = 0.0, lam_used = 0.0, hard_pred = 0.0;
+    host_g_valid = false;
     for (int inner = 0; inner < 80; ++inner) {
       if (!(h_at_zero && lam == 0.0)) {
         form_shifted_kernel<<<N, 256, 0, s>>>(W.Sinv, N, W.mblk, C.ld, C.lo, lam, W.H, nullptr);
@@ -412,14 +444,20 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
       int info = 0;
       PPBO_HIP_CHECK(ctx, hipMemcpyAsync(&info, W.d_info, sizeof(int), hipMemcpyDeviceToHost, s));
       PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+      if (verbose > 1) printf("    [inner %d] lam %.6e info %d lb %.3e ub %.3e radius %.3e\n", inner, lam, info, lb, ub, radius);
       if (info != 0) {
+        any_failed = true;
         lb = std::fmax(lb, lam);
         if (lb == 0.0) lb = 1e-14 * std::fmax(st_inf, 1e-300);   // lam = 0 is ruled out from now on
         if (ub <= lb) ub = 2.0 * lb + 1e-12;
         if (warm > lb && warm < ub) { lam = warm; warm = 0.0; }
+        else if (std::isfinite(best_pd)) lam = std::sqrt(lb * best_pd);    // between the failure and a known PD shift
+        else if (had_guess) lam = 2.0 * lb;                                // right order of magnitude: double, do not
+                                                                           // jump to the (very loose) Gershgorin mean
         else lam = std::fmax(std::sqrt(lb * ub), lb + 0.01 * (ub - lb));
         continue;
       }
+      best_pd = std::fmin(best_pd, lam);
       if (int rc = ppbo_trtri_async(ctx, W.H, N, N, W.Linv, N, s)) return rc;
       if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, C.g, W.w, 0, 1, s)) return rc;   // w = L^-1 g
       if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.w, W.u, 1, 1, s)) return rc;   // u = L^-T w
@@ -436,10 +474,59 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
                               gtp, qn2, it);
       have_step = true;
       lam_used = lam;
+      if (verbose > 1) printf("    [inner %d]   |p| %.6e (radius %.3e)\n", inner, pn, radius);
       if (pn <= radius && lam == 0.0) { boundary = false; break; }
       if (std::fabs(pn - radius) <= k_easy * radius) break;
       double lam_new = lam + (pn * pn / qn2) * (pn - radius) / radius;
-      if (pn < radius) ub = lam; else lb = lam;
+      if (pn < radius) {
+        // Inside the region with lam > 0: the solution sits next to the pole -lambda_min(H) ("hard case",
+        // Conn/Gould/Toint 7.3.1).  Two inverse iterations with the factor just computed give the eigenvector z
+        // of the smallest eigenvalue s2 of H + lam I; p + tau z on the boundary is accepted when it changes the
+        // model by less than k_hard, and lam - s2 is a tight lower bound on the admissible shifts.
+        std::vector<double>& hp = host_p; std::vector<double>& hz = host_z; std::vector<double>& hl = host_lz;
+        if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.p, W.w, 0, 1, s)) return rc;
+        if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.w, W.u, 1, 1, s)) return rc;
+        if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.u, W.w, 0, 1, s)) return rc;
+        if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.w, W.u, 1, 1, s)) return rc;      // u ~ eigenvector
+        if (int rc = ppbo_gemv_async(ctx, W.H, N, N, W.u, W.q, 1, 1, s)) return rc;         // q = L^T u
+        PPBO_HIP_CHECK(ctx, hipMemcpyAsync(hp.data(), W.p, vbytes, hipMemcpyDeviceToHost, s));
+        PPBO_HIP_CHECK(ctx, hipMemcpyAsync(hz.data(), W.u, vbytes, hipMemcpyDeviceToHost, s));
+        PPBO_HIP_CHECK(ctx, hipMemcpyAsync(hl.data(), W.q, vbytes, hipMemcpyDeviceToHost, s));
+        if (!host_g_valid) PPBO_HIP_CHECK(ctx, hipMemcpyAsync(host_g.data(), C.g, vbytes, hipMemcpyDeviceToHost, s));
+        PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        host_g_valid = true;
+        double zn2 = 0.0, lz2 = 0.0, pz = 0.0, gz = 0.0;
+        for (int i = 0; i < N; ++i) { zn2 += hz[i] * hz[i]; lz2 += hl[i] * hl[i]; pz += hp[i] * hz[i]; gz += host_g[i] * hz[i]; }
+        if (zn2 > 0.0 && std::isfinite(zn2)) {
+          const double zn = std::sqrt(zn2);
+          const double s2 = lz2 / zn2;                       // z'(H + lam I)z for the unit vector
+          pz /= zn; gz /= zn;
+          const double cterm = pn * pn - radius * radius;    // < 0
+          const double disc = std::sqrt(std::fmax(pz * pz - cterm, 0.0));
+          const double ta = -pz + disc, tb = -pz - disc;
+          const double tau = (std::fabs(ta) < std::fabs(tb)) ? ta : tb;
+          const double quad = -gtp;                          // p'(H + lam I)p
+          const double rel = tau * tau * s2 / (quad + lam * radius * radius);
+          if (rel <= k_hard) {
+            for (int i = 0; i < N; ++i) hp[i] += tau * hz[i] / zn;
+            PPBO_HIP_CHECK(ctx, hipMemcpyAsync(W.p, hp.data(), vbytes, hipMemcpyHostToDevice, s));
+            restep_kernel<<<1, 1024, 0, s>>>(W.p, C.g, C.f, N, T.f, W.sc + 16);
+            PPBO_HIP_CHECK(ctx, hipMemcpyAsync(W.hsc, W.sc + 16, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+            PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            const double gtp_new = W.hsc[1];
+            // model decrease of the modified step: -(g'p' + 1/2 p'Hp'), p'Hp' = p'(H+lam I)p' - lam |p'|^2
+            hard_pred = -0.5 * gtp_new + 0.5 * tau * gz - 0.5 * tau * tau * s2 + 0.5 * lam * radius * radius;
+            pn = std::sqrt(W.hsc[0]);
+            gtp = gtp_new;
+            used_hard = true;
+            break;
+          }
+          lb = std::fmax(lb, lam - s2);
+        }
+        ub = lam;
+      } else {
+        lb = lam;
+      }
       if (!(lb < lam_new && lam_new < ub)) {
         // the secular-equation Newton step left the bracket; if lam = 0 is still possible (no failed
         // factorization there) and the step is inside the region, the interior Newton step is next
@@ -455,8 +542,9 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
     prev_lam = lam_used;
     prev_radius = radius;
     prev_boundary = boundary;
+    prev_failed = any_failed;
     // (H + lam I) p = -g  =>  p'Hp = -g'p - lam |p|^2
-    const double pred = -0.5 * gtp + 0.5 * lam_used * pn * pn;
+    const double pred = used_hard ? hard_pred : (-0.5 * gtp + 0.5 * lam_used * pn * pn);
     if (!(pred > 0.0)) break;
     if (int rc = eval_point(W, T, W.p, C.v)) return rc;
     // phi(f) - phi(f+p) = -1/2 p'(Sf + S(f+p)) + (Tlik(f+p) - Tlik(f)), from small quantities

@@ -219,7 +219,7 @@ class Engine:
         f0 = self.dev(f_init).reshape(-1)
         N = f0.numel()
         out = self.empty(N)
-        opts = _lib.FitOpts(float(gtol), int(maxiter), int(bool(verbose)))
+        opts = _lib.FitOpts(float(gtol), int(maxiter), int(verbose))
         st = _lib.FitStats()
         rc = self.lib.ppbo_fit_fmap(self.ctx, _ptr(Sigma_inv), N, m, float(sigma), _ptr(f0), C.byref(opts), _ptr(out),
                                     C.byref(st), self._stream())
