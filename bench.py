@@ -34,7 +34,7 @@ def synth_model_inputs(cfg):
     return g
 
 
-def cpu_baseline(g, M_sample, seconds_budget=25.0):
+def cpu_baseline(g, M_sample, seconds_budget=25.0, gpu_check=None):
     """Oracle (CPU restatement of the reference) timed on the host cores on a bounded sample."""
     from oracle import ppbo_oracle as orc
     import threadpoolctl
@@ -73,12 +73,21 @@ def cpu_baseline(g, M_sample, seconds_budget=25.0):
     fm, _ = orc.fit_fmap_trust_exact(g["f_init"], Si, m, th[0])
     _ = orc.posterior_covariance(Si, fm, m, th[0])
     cpu_fit_ms = (time.perf_counter() - tf) * 1e3
+    parity = None
+    if gpu_check is not None:   # in-situ parity of the timed path against the oracle on a subsample
+        Xs, mu_gpu, var_gpu = gpu_check
+        mu_o, var_o = orc.predict_mean_var(Xs, X, th, alpha, A, kern)
+        parity = {"candidates": int(Xs.shape[0]),
+                  "mu_max_rel_err": float(np.max(np.abs(mu_gpu - mu_o)) / np.max(np.abs(mu_o))),
+                  "var_max_err_over_sf2": float(np.max(np.abs(var_gpu - var_o)) / float(th[2]) ** 2),
+                  "tolerance": 1e-5}
     info = threadpoolctl.threadpool_info()
     nthreads = max([i.get("num_threads", 1) for i in info] + [1])
     return dict(value=opt_rate, unit="evals/s", cores=int(nthreads), kind="port",
                 sample=f"{reps}x{M_sample} candidates mean+var+EI+argmax, cached alpha/A (optimised-CPU mode); "
                        f"faithful mu_pred per candidate: {faithful_rate:.0f} evals/s over {n_f} candidates",
-                faithful_mu_pred_evals_per_s=faithful_rate, host_cpus=os.cpu_count(), gp_fit_ms=cpu_fit_ms)
+                faithful_mu_pred_evals_per_s=faithful_rate, host_cpus=os.cpu_count(), gp_fit_ms=cpu_fit_ms,
+                parity_vs_oracle=parity)
 
 
 def main():
@@ -267,7 +276,12 @@ def main():
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(g, 2048)
+            # the oracle uses the reference's fMAP from the fixture; score the same subsample with that model
+            Sinv_d = eng.pd_inverse(eng.gram(Xd, th, kern))
+            post_ref = eng.posterior(Xd, th, kern, Sinv_d, g["fMAP"], m)
+            Xs = np.random.default_rng(11).random((256, D))
+            chk = eng.predict(post_ref, Xs, want_best=False)
+            line["cpu_baseline"] = cpu_baseline(g, 2048, gpu_check=(Xs, chk["mu"].cpu().numpy(), chk["var"].cpu().numpy()))
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
