@@ -7,11 +7,14 @@
 //   mu(x)  = k*' alpha
 //   var(x) = sigma_f^2 - k*' A k*,  A = Sigma^-1 - Sigma^-1 P Sigma^-1  (gp_model.py:449)
 //          = sigma_f^2 + k*' Lambda k* + |G k*|^2                        (Woodbury, same operator)
-// Pass 1 (kstar_kernel, VALU): one lane = two candidates held in registers, X rows
-//   arrive through scalar loads; writes K*[N, Mc] (j-major) once and reduces mu and
-//   k*'Lambda k* in registers (no cross-lane traffic).
-// Pass 2 (quadform_kernel, fp64 MFMA): Y = G K* on 128x128 tiles, K range cut at the
-//   block-triangular edge, epilogue = column sums of Y^2 into per-row-tile slabs.
+// Pass 1 (kstar_kernel, VALU): one lane = two candidates held in registers, X rows staged in LDS
+//   and read as broadcasts (direct differences: alpha has cond(Sigma)-size entries, so K* keeps full
+//   fp64 accuracy); writes K*[N, Mc] (j-major) once and reduces mu and k*'Lambda k* in registers.
+// Pass 2 (quadform_kernel, fp64 MFMA): Y = G K* on 128x128 tiles (8 wavefronts of 32x64), K range cut
+//   at the block-triangular edge per wavefront, epilogue = column sums of Y^2 into per-row-tile slabs.
+//   Workgroups are ordered candidate-tile-fastest in chunks of 64 tiles (PPBO_QF_ORDER, default 258):
+//   all resident workgroups stream the same G row panel out of L2 while their K* chunk sits in the
+//   Infinity Cache.  PPBO_QF_VARIANT (default 2) selects the measured tile shapes, see DESIGN.md.
 // Pass 3 (score_kernel): slab sums -> var, score, per-block argmax; (argmax_final_kernel) -> 1 value.
 #include "gemm_f64.h"
 #include "linalg.h"
