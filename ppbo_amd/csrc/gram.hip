@@ -1,12 +1,11 @@
 // K1 / K2: Gram matrix (symmetric, shrinkage fused) and raw cross-covariance.
 //   reference: kernels.py:3-53 (dist, SE/RQ/camphor), gp_model.py:147-155,
 //              misc.py:71-88 (regularize_covariance == closed-form shrink).
-// Layout: X[N,D] row-major fp64 in HBM.  One 256-thread workgroup produces one
-// 64x64 output tile; the two 64-row operand panels are staged in LDS transposed
-// ([D][64]) so a lane's four columns are one 32-byte LDS read.  gram only visits
-// tiles on/above the diagonal and mirrors them through an LDS transpose, so
-// every HBM store is a full 512-byte row segment.  HBM-write bound:
-// algorithmic bytes = 8 N^2 + 8 N D.
+// Layout: X[N,D] row-major fp64 in HBM.  One 256-thread workgroup produces one 64x64 output tile;
+// gram only visits tiles on/above the diagonal and writes the mirror image itself, every HBM store
+// completing whole 128-byte lines.  SE/RQ tiles run on the matrix cores (gram_mfma_kernel), the
+// camphor kernel on the vector ALUs (gram_kernel).  HBM-write bound: algorithmic bytes = 8 N^2 + 8 N D;
+// the write-only floor of the chip at these sizes is measured by tools/store_floor.hip.
 #include "common.h"
 
 namespace {
@@ -128,23 +127,59 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ X,
   }
 }
 
-// SE / RQ Gram tile with the whole squared distance on the fp64 matrix cores.  Rows are
-// augmented so that one MFMA chain yields r^2 directly (the reference's expansion formula,
-// kernels.py:7-10, clipped at 0):
-//   a_i = ( x_i , |x_i|^2 , 1 , 0.. )      b_j = ( -2 x_j , 1 , |x_j|^2 , 0.. )      a_i . b_j = r_ij^2
-// DP = D padded to a multiple of 4 (compile time), KA = DP + 4 the augmented depth.  The panel
-// loads, the fragment reads and the MFMA chain are fully unrolled: one HBM round trip, one LDS
-// round trip, KA/4 * 4 MFMAs per wave, then clip + exp + shrink.  Wave w owns rows 16w..16w+15.
-// The finished tile is staged in LDS (aliasing the dead panels) so that the tile and its mirror
-// both leave as full 512-byte row segments.
+// exp(x) for x <= 0 (the SE kernel's argument): Cody-Waite reduction by ln2, degree-11 near-minimax
+// polynomial on |r| <= ln2/2 (fit error 3e-18, tools/expfit.py), scaling by v_ldexp_f64.  18 VALU
+// instructions and no special-case branches (the library exp spends as many again on range checks);
+// measured against 50-digit arithmetic: <= 1 ulp.
+__device__ __forceinline__ double exp_nonpos(double x) {
+  x = fmax(x, -750.0);                       // exp underflows to 0 below -745.2; keeps (int)n in range
+  const double n = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double q = 0x1.af632a0f7e2cep-26;
+  q = __builtin_fma(q, r, 0x1.28b4101c77212p-22);
+  q = __builtin_fma(q, r, 0x1.71ddf56d8deb5p-19);
+  q = __builtin_fma(q, r, 0x1.a01991a10d9aep-16);
+  q = __builtin_fma(q, r, 0x1.a01a01b1461c5p-13);
+  q = __builtin_fma(q, r, 0x1.6c16c1880029fp-10);
+  q = __builtin_fma(q, r, 0x1.111111110f21ep-7);
+  q = __builtin_fma(q, r, 0x1.555555554f0bap-5);
+  q = __builtin_fma(q, r, 0x1.555555555555ap-3);
+  q = __builtin_fma(q, r, 0x1.0000000000011p-1);
+  q = __builtin_fma(q, r, 1.0);
+  q = __builtin_fma(q, r, 1.0);
+  return ldexp(q, (int)n);
+}
+
+template <int KID>
+__device__ __forceinline__ double gram_finish(double r2, const KernParams& p, double scale) {
+  if (KID == PPBO_KERNEL_SE) return scale * exp_nonpos(-p.c0 * r2);
+  const double t = 1.0 + r2 * p.c0;
+  return scale / (t * t);
+}
+
+// SE / RQ Gram tile with the pairwise dot products on the fp64 matrix cores and the reference's
+// expansion  r_ij^2 = (|x_i|^2 + |x_j|^2) - 2 x_i.x_j  (kernels.py:7-10), clipped at 0.  The MFMA chain
+// multiplies x_i by (-2 x_j): products and accumulation order are the same for (i,j) and (j,i), and
+// the norm sum commutes, so the matrix is bitwise symmetric by construction.
+// DP = D padded to a multiple of 4 (compile time).  One 256-thread workgroup owns one 64x64 tile on or
+// above the diagonal; wave w owns its rows 16w..16w+15.  After the single barrier that publishes the
+// two operand panels the waves are independent: per 16x16 sub-tile a wave runs DP/4 MFMAs, finishes
+// its four entries per lane, stores them straight from registers (16 lanes = one 128-byte line), and
+// -- off the diagonal -- transposes the sub-tile through a private 2 KB LDS strip and stores the
+// mirror image as 16-byte pieces (8 lanes = one line).  Stores therefore start after the first
+// quarter of the wave's arithmetic and overlap the rest.  HBM-write bound: 8 N^2 + 8 N D bytes.
 template <int KID, int DP>
 __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict__ X, int N, int D, KernParams p,
                                                          double shrink, double* __restrict__ Sigma, int nt) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int KA = DP + 4, LD = KA + 2;
-  double* Xa = smem;              // [64][LD]
-  double* Xb = smem + TS * LD;    // [64][LD]
-  double* Tt = smem;              // [64][TP] (aliases the panels once the MFMAs are done)
+  constexpr int LD = DP + 2;       // 2*odd: fragment reads and panel writes are bank-conflict free
+  constexpr int LT = 18;           // transpose strip row pitch (conflict-free b64 writes, 16-byte aligned rows)
+  double* Xa = smem;               // [64][LD]
+  double* Xb = Xa + TS * LD;       // [64][LD]  (-2 x_j)
+  double* na = Xb + TS * LD;       // [64] |x_i|^2
+  double* nb = na + TS;            // [64] |x_j|^2
+  double* Tw = nb + TS;            // [4 waves][16][LT]
 
   const int t = blockIdx.x;
   const double q = 2.0 * nt + 1.0;
@@ -175,78 +210,74 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
     }
     sa += __shfl_xor(sa, 1, 64); sa += __shfl_xor(sa, 2, 64);
     sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64);
-    // augmentation columns DP..DP+3, one per lane of the row quad
-    Xa[r * LD + DP + part] = (part == 0) ? sa : ((part == 1) ? 1.0 : 0.0);
-    Xb[r * LD + DP + part] = (part == 0) ? 1.0 : ((part == 1) ? sb : 0.0);
+    if (part == 0) { na[r] = sa; nb[r] = sb; }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  double4_t acc[4];
+  double af[DP / 4], nai[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
-  {
-    double af[KA / 4], bf[4][KA / 4];
+  for (int kk = 0; kk < DP / 4; ++kk) af[kk] = Xa[(w * 16 + lr) * LD + kk * 4 + lk];
 #pragma unroll
-    for (int kk = 0; kk < KA / 4; ++kk) af[kk] = Xa[(w * 16 + lr) * LD + kk * 4 + lk];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int kk = 0; kk < KA / 4; ++kk) bf[j][kk] = Xb[(j * 16 + lr) * LD + kk * 4 + lk];
-#pragma unroll
-    for (int kk = 0; kk < KA / 4; ++kk)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[j][kk], acc[j], 0, 0, 0);
-  }
-  __syncthreads();   // panels are dead from here
+  for (int r = 0; r < 4; ++r) nai[r] = na[w * 16 + lk + 4 * r];
+
   const double one_minus = 1.0 - shrink;
+  const double scale = one_minus * p.sf2;
   const double diagv = one_minus * p.sf2 + shrink * p.sf2;
+  const bool vec_ok = ((N & 1) == 0);
+  const bool full = (i0 + TS <= N) && (j0 + TS <= N);
+  double* Ts = Tw + w * 16 * LT;
+  // direct piece: rows lk+4r of the wave's strip, column lr of sub-tile j
+  double* ddst = Sigma + (size_t)(i0 + w * 16 + lk) * N + j0 + lr;
+  // mirror piece: lane = (row c = lane>>3 (+8), column pair 2*(lane&7)) of the transposed sub-tile
+  const int mc = lane >> 3, mp = (lane & 7) * 2;
+  double* mdst = Sigma + (size_t)(j0 + mc) * N + i0 + w * 16 + mp;
+
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int col = j * 16 + lr;
+    double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = w * 16 + lk + 4 * r;
-      double r2 = acc[j][r];
-      r2 = r2 > 0.0 ? r2 : 0.0;
-      const double k = kern_finish<KID>(r2, p);
-      Tt[row * TP + col] = ((i0 + row) == (j0 + col)) ? diagv : one_minus * k;
-    }
-  }
-  __syncthreads();
-  // stores: lane = one 16-byte column pair, 32 lanes = one full 512-byte row segment
-  const int c2 = (threadIdx.x & 31) * 2, r0 = threadIdx.x >> 5;
-  const bool vec_ok = ((N & 1) == 0);
+    for (int kk = 0; kk < DP / 4; ++kk)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], Xb[(j * 16 + lr) * LD + kk * 4 + lk], acc, 0, 0, 0);
+    const double nbj = nb[j * 16 + lr];
+    double v[4];
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    const int r = a * 8 + r0;
-    const int gi = i0 + r, gj = j0 + c2;
-    if (gi >= N) continue;
-    double2 v = *reinterpret_cast<const double2*>(Tt + r * TP + c2);
-    if (bi == bj) {   // diagonal tile: (acc + n_i) + n_j is not bitwise (acc + n_j) + n_i -> mirror the upper half
-      if (r > c2) v.x = Tt[c2 * TP + r];
-      if (r > c2 + 1) v.y = Tt[(c2 + 1) * TP + r];
-    }
-    double* dst = Sigma + (size_t)gi * N + gj;
-    if (vec_ok && gj + 1 < N) *reinterpret_cast<double2*>(dst) = v;
-    else {
-      if (gj < N) dst[0] = v.x;
-      if (gj + 1 < N) dst[1] = v.y;
-    }
-  }
-  if (bi == bj) return;
+    for (int r = 0; r < 4; ++r) v[r] = gram_finish<KID>(fmax(acc[r] + (nai[r] + nbj), 0.0), p, scale);
+    if (bi == bj && j == w) {
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    const int r = a * 8 + r0;           // row of the mirrored tile = column of Tt
-    const int gi = j0 + r, gj = i0 + c2;
-    if (gi >= N) continue;
-    const double vx = Tt[c2 * TP + r], vy = Tt[(c2 + 1) * TP + r];
-    double* dst = Sigma + (size_t)gi * N + gj;
-    if (vec_ok && gj + 1 < N) *reinterpret_cast<double2*>(dst) = make_double2(vx, vy);
-    else {
-      if (gj < N) dst[0] = vx;
-      if (gj + 1 < N) dst[1] = vy;
+      for (int r = 0; r < 4; ++r)
+        if (lk + 4 * r == lr) v[r] = diagv;
     }
+    if (full) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ddst[(size_t)(4 * r) * N + j * 16] = v[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (i0 + w * 16 + lk + 4 * r < N && j0 + j * 16 + lr < N) ddst[(size_t)(4 * r) * N + j * 16] = v[r];
+    }
+    if (bi == bj) continue;
+    // transpose through the wave's private strip; LDS traffic of one wave is ordered, the fences
+    // only keep the compiler from moving the accesses across each other
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ts[lr * LT + lk + 4 * r] = v[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = mc + 8 * h;
+      const double2 m = *reinterpret_cast<const double2*>(Ts + c * LT + mp);
+      double* dst = mdst + (size_t)(j * 16 + 8 * h) * N;
+      const int gi = j0 + j * 16 + c, gj = i0 + w * 16 + mp;
+      if (full && vec_ok) *reinterpret_cast<double2*>(dst) = m;
+      else if (gi < N) {
+        if (gj < N) dst[0] = m.x;
+        if (gj + 1 < N) dst[1] = m.y;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -309,8 +340,8 @@ int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, con
   if (kernel_id != PPBO_KERNEL_CAMPHOR) {
 #define GM_LAUNCH(DPV)                                                                                       \
   do {                                                                                                       \
-    constexpr int LDv = DPV + 6;                                                                             \
-    constexpr int body = (TS * TP > 2 * TS * LDv) ? TS * TP : 2 * TS * LDv;                                  \
+    constexpr int LDv = DPV + 2;                                                                             \
+    constexpr int body = 2 * TS * LDv + 2 * TS + 4 * 16 * 18;                                                \
     const size_t lds = (size_t)body * sizeof(double);                                                        \
     if (kernel_id == PPBO_KERNEL_SE) {                                                                       \
       if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gram_mfma_kernel<PPBO_KERNEL_SE, DPV>,     \
