@@ -13,6 +13,7 @@ using GCSmall = Cfg<2, 2, 2, 2>;   // 64 x 64 tile, 4 wavefronts of 32 x 32: sho
 
 template <class GC, int ALAY, int BLAY>
 __global__ __launch_bounds__(GC::NT, (GC::NT == 512) ? 4 : 2) void dgemm_kernel(GemmArgs g) {
+  constexpr bool PRELOAD = (GC::NT == 256);   // the small-tile configuration (latency-bound panel updates)
   constexpr int BM = GC::BM, BN = GC::BN;
   if (g.batch > 1) {
     g.A += (size_t)blockIdx.y * g.strideA;
@@ -35,7 +36,24 @@ __global__ __launch_bounds__(GC::NT, (GC::NT == 512) ? 4 : 2) void dgemm_kernel(
   else if (g.klo_mode == 2) kbeg = n0;
   kbeg &= ~1;
   double4_t acc[GC::TM][GC::TN];
-  zero_acc<GC>(acc);
+  // rank-k updates C -= A B^T (alpha = -beta) start from the accumulators holding -C: the read of C is
+  // issued with the first operand tiles instead of as a second memory round trip after the main loop,
+  // and alpha * (A B - C) = alpha * A B + beta * C
+  const bool preload = PRELOAD && (g.beta != 0.0) && (g.alpha == -g.beta || g.alpha == g.beta);
+  if (preload) {
+    const double sgn = (g.alpha == g.beta) ? 1.0 : -1.0;
+#pragma unroll
+    for (int i = 0; i < GC::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < GC::TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + acc_row<GC>(i, r), col = n0 + acc_col<GC>(j);
+          acc[i][j][r] = (row < g.M && col < g.N) ? sgn * g.C[(size_t)row * g.ldc + col] : 0.0;
+        }
+  } else {
+    zero_acc<GC>(acc);
+  }
   mainloop<GC, ALAY, BLAY>(g.A, g.lda, g.B, g.ldb, g.M, g.N, m0, n0, kbeg, kend, acc);
 #pragma unroll
   for (int i = 0; i < GC::TM; ++i)
@@ -49,7 +67,7 @@ __global__ __launch_bounds__(GC::NT, (GC::NT == 512) ? 4 : 2) void dgemm_kernel(
         if (col >= g.N) continue;
         double* c = g.C + (size_t)row * g.ldc + col;
         double v = g.alpha * acc[i][j][r];
-        if (g.beta != 0.0) v += g.beta * (*c);
+        if (!preload && g.beta != 0.0) v += g.beta * (*c);
         *c = v;
       }
     }

@@ -127,30 +127,6 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ X,
   }
 }
 
-// exp(x) for x <= 0 (the SE kernel's argument): Cody-Waite reduction by ln2, degree-11 near-minimax
-// polynomial on |r| <= ln2/2 (fit error 3e-18, tools/expfit.py), scaling by v_ldexp_f64.  18 VALU
-// instructions and no special-case branches (the library exp spends as many again on range checks);
-// measured against 50-digit arithmetic: <= 1 ulp.
-__device__ __forceinline__ double exp_nonpos(double x) {
-  x = fmax(x, -750.0);                       // exp underflows to 0 below -745.2; keeps (int)n in range
-  const double n = __builtin_rint(x * 1.4426950408889634);
-  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
-  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
-  double q = 0x1.af632a0f7e2cep-26;
-  q = __builtin_fma(q, r, 0x1.28b4101c77212p-22);
-  q = __builtin_fma(q, r, 0x1.71ddf56d8deb5p-19);
-  q = __builtin_fma(q, r, 0x1.a01991a10d9aep-16);
-  q = __builtin_fma(q, r, 0x1.a01a01b1461c5p-13);
-  q = __builtin_fma(q, r, 0x1.6c16c1880029fp-10);
-  q = __builtin_fma(q, r, 0x1.111111110f21ep-7);
-  q = __builtin_fma(q, r, 0x1.555555554f0bap-5);
-  q = __builtin_fma(q, r, 0x1.555555555555ap-3);
-  q = __builtin_fma(q, r, 0x1.0000000000011p-1);
-  q = __builtin_fma(q, r, 1.0);
-  q = __builtin_fma(q, r, 1.0);
-  return ldexp(q, (int)n);
-}
-
 template <int KID>
 __device__ __forceinline__ double gram_finish(double r2, const KernParams& p, double scale) {
   if (KID == PPBO_KERNEL_SE) return scale * exp_nonpos(-p.c0 * r2);

@@ -251,6 +251,247 @@ __global__ __launch_bounds__(256) void trsm_mfma_kernel(double* __restrict__ A, 
   }
 }
 
+
+// ---- third generation: one kernel per panel.  Every workgroup of the panel launch factors the 64x64
+// diagonal block ITSELF (the same 4-wave blocked factorization as potf2_block, in its own LDS) and then
+// solves its 64 rows below it, so the diagonal factor never travels between workgroups and the
+// potf2 -> trsm kernel boundary (launch gap + ramp, ~5 us of a ~40 us panel step) disappears.  The
+// redundant flops are free: a panel launch has at most N/64 - 1 workgroups on 256 CUs.
+// Nobody may overwrite A_kk while another workgroup can still be reading it, so workgroup 0 writes
+// L_kk to a side buffer (diag_out, one 64x64 slot per panel) that is scattered back once at the end.
+// inverse of the 16x16 lower-triangular diagonal block b of the factored panel block (lane = column c < 16);
+// Rinv holds the reciprocal pivots left by the factorization
+__device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, const double* __restrict__ Rinv,
+                                              double* __restrict__ Li, int b, int lane) {
+  if (lane >= 16) return;
+  const int c = lane, c0 = 16 * b;
+  double y[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < r; ++k) v -= Ab[(c0 + r) * BLD + c0 + k] * y[k];
+    y[r] = (r >= c) ? v * Rinv[c0 + r] : 0.0;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Li[(b * 16 + r) * 18 + c] = y[r];
+}
+
+constexpr int PANEL_LDS = (NB * BLD + 4 * 16 * 18 + 4 * 16 * BLD + NB + 2) * (int)sizeof(double);
+
+__global__ __launch_bounds__(256) void panel_fused_kernel(double* __restrict__ A, int lda, int N, int k0,
+                                                          double* __restrict__ diag_out, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double plds[];
+  double* Ab = plds;                    // [64][BLD]  A_kk -> L_kk
+  double* Li = Ab + NB * BLD;           // [4][16][18] inverses of the 16x16 diagonal blocks
+  double* Xs = Li + 4 * 16 * 18;        // [4 waves][16][BLD]
+  double* Rinv = Xs + 4 * 16 * BLD;     // [64] 1 / l_jj
+  int& s_fail = *reinterpret_cast<int*>(Rinv + NB);   // all LDS in the dynamic region: keeps its base 16-byte aligned
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  // every global read of the kernel is issued up front: the error word, the diagonal block, and this
+  // wavefront's 16 panel rows (needed only after the factorization) -- one memory latency instead of three
+  const int info_in = *info;
+  double a11[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int e = t + 256 * q, r = e >> 6, c = e & 63;
+    a11[q] = (c <= r) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;
+  }
+  const int row0 = k0 + NB + (blockIdx.x * 4 + wave) * 16;
+  double4_t rowv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gr = row0 + lk + 4 * r;
+      rowv[c][r] = (gr < N) ? A[(size_t)gr * lda + k0 + 16 * c + lr] : 0.0;
+    }
+  if (info_in != 0) return;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int e = t + 256 * q;
+    Ab[(e >> 6) * BLD + (e & 63)] = a11[q];
+  }
+  if (t == 0) s_fail = 0;
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int c0 = 16 * s;
+    if (wave == 0) {
+      // left-looking within the slab: column j first collects the contributions of columns k < j -- the
+      // multipliers it needs all sit in ONE lane (row c0+j) and are consumed as they are broadcast.  (Written
+      // right-looking, the compiler sinks every update to its use anyway and then spills the 120 live
+      // broadcasts of a slab from SGPRs to VGPR lanes.)  A lone wavefront retires ~1 instruction per 8
+      // cycles here, so the slab costs its instruction count: ~700 -> 2.3 us.
+      double a[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a[j] = Ab[lane * BLD + c0 + j];
+      int fail = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double v = a[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v -= a[k] * lane_bcast(a[k], c0 + j);
+        const double d = lane_bcast(v, c0 + j);
+        if (!(d > 0.0) && fail == 0) fail = c0 + j + 1;
+        const double rs = rsqrt_refined(d);
+        a[j] = (lane == c0 + j) ? d * rs : v * rs;
+        if (lane == c0 + j) Rinv[c0 + j] = rs;
+      }
+      if (lane >= c0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Ab[lane * BLD + c0 + j] = (c0 + j <= lane) ? a[j] : 0.0;
+      }
+      if (fail && lane == 0 && s_fail == 0) s_fail = fail;
+    } else if (wave == 3 && s > 0) {
+      // inverse of the PREVIOUS slab's 16x16 diagonal block (lane = column) while wave 0 factors this one
+      invert_diag16(Ab, Rinv, Li, s - 1, lane);
+    }
+    __syncthreads();
+    if (s_fail) break;
+    int tile = 0;
+#pragma unroll
+    for (int cb = 1; cb < 4; ++cb) {
+#pragma unroll
+      for (int rb = 1; rb < 4; ++rb) {
+        if (cb <= s || rb < cb) continue;
+        if ((tile++ & 3) != wave) continue;
+        double4_t acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Ab[(16 * rb + lk + 4 * r) * BLD + 16 * cb + lr];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const double av = -Ab[(16 * rb + lr) * BLD + c0 + kk * 4 + lk];
+          const double bv = Ab[(16 * cb + lr) * BLD + c0 + kk * 4 + lk];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ab[(16 * rb + lk + 4 * r) * BLD + 16 * cb + lr] = acc[r];
+      }
+    }
+    if (s < 3) __syncthreads();
+  }
+  if (!s_fail && wave == 0) invert_diag16(Ab, Rinv, Li, 3, lane);
+  __syncthreads();
+  if (s_fail) {
+    if (blockIdx.x == 0 && t == 0) *info = k0 + s_fail;
+    return;
+  }
+  if (blockIdx.x == 0) {
+    for (int e = t; e < NB * NB; e += 256) diag_out[e] = Ab[(e >> 6) * BLD + (e & 63)];
+  }
+  if (row0 >= N) return;
+  double* xs = Xs + wave * 16 * BLD;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double4_t acc = rowv[c];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (p >= c) continue;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const double av = -xs[lr * BLD + 16 * p + kk * 4 + lk];
+        const double bv = Ab[(16 * c + lr) * BLD + 16 * p + kk * 4 + lk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xs[(lk + 4 * r) * BLD + 16 * c + lr] = acc[r];
+    __builtin_amdgcn_wave_barrier();
+    double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const double av = xs[lr * BLD + 16 * c + kk * 4 + lk];
+      const double bv = Li[(c * 16 + lr) * 18 + kk * 4 + lk];
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xs[(lk + 4 * r) * BLD + 16 * c + lr] = x[r];
+      const int gr = row0 + lk + 4 * r;
+      if (gr < N) A[(size_t)gr * lda + k0 + 16 * c + lr] = x[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+
+// Trailing update of one panel step, C -= P P^T with P the freshly solved (rest x 64) panel: one 64x64 tile
+// of the lower triangle per workgroup.  The generic engine streams K in 16-deep stages with one stage of
+// prefetch; at K = 64 that is four dependent memory round trips for 0.5 MFLOP of work.  Here both panel
+// blocks and the C tile are requested at once (one round trip), staged once, and the 64 MFMAs per
+// wavefront run from LDS without further barriers.  Tiles are enumerated by folding the triangle into a
+// (nt+1) x ceil(nt/2) rectangle.
+constexpr int SYRK_LDS = 2 * NB * BLD * (int)sizeof(double);
+
+__global__ __launch_bounds__(256) void syrk64_kernel(double* __restrict__ A, int lda, int N, int k0,
+                                                     const int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double slds[];
+  double* Pi = slds;               // [64][BLD] rows of the panel for the tile's rows
+  double* Pj = slds + NB * BLD;    // [64][BLD] ... for the tile's columns
+  const int rest0 = k0 + NB, rest = N - rest0, nt = (rest + NB - 1) / NB;
+  const int c = blockIdx.x, tr = blockIdx.y;
+  int ti, tj;      // ti >= tj
+  if (c <= tr) { ti = tr; tj = c; }
+  else { ti = nt - 1 - tr; tj = c - tr - 1; if (ti == tr || tj > ti) return; }
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int i0 = rest0 + ti * NB, j0 = rest0 + tj * NB;
+  const int info_in = *info;
+  double pi[16], pj[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int e = t + 256 * q, r = e >> 6, cc = e & 63;
+    pi[q] = (i0 + r < N) ? A[(size_t)(i0 + r) * lda + k0 + cc] : 0.0;
+    pj[q] = (ti != tj && j0 + r < N) ? A[(size_t)(j0 + r) * lda + k0 + cc] : 0.0;
+  }
+  double4_t acc[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gr = i0 + 16 * wave + lk + 4 * r, gc = j0 + 16 * jt + lr;
+      acc[jt][r] = (gr < N && gc < N) ? A[(size_t)gr * lda + gc] : 0.0;
+    }
+  if (info_in != 0) return;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int e = t + 256 * q;
+    Pi[(e >> 6) * BLD + (e & 63)] = pi[q];
+    if (ti != tj) Pj[(e >> 6) * BLD + (e & 63)] = pj[q];
+  }
+  __syncthreads();
+  const double* Pb = (ti != tj) ? Pj : Pi;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const double av = -Pi[(16 * wave + lr) * BLD + 4 * kk + lk];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+      acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pb[(16 * jt + lr) * BLD + 4 * kk + lk], acc[jt], 0, 0, 0);
+  }
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gr = i0 + 16 * wave + lk + 4 * r, gc = j0 + 16 * jt + lr;
+      if (gr < N && gc < N) A[(size_t)gr * lda + gc] = acc[jt][r];
+    }
+}
+
+// diagonal factors parked by panel_fused_kernel -> lower triangles of A's diagonal blocks
+__global__ __launch_bounds__(256) void scatter_diag_kernel(double* __restrict__ A, int lda,
+                                                           const double* __restrict__ diag, const int* __restrict__ info) {
+  if (*info != 0) return;
+  const int k0 = blockIdx.x * NB;
+  const double* src = diag + (size_t)blockIdx.x * NB * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e - r * NB;
+    if (c <= r) A[(size_t)(k0 + r) * lda + k0 + c] = src[e];
+  }
+}
+
 // inverse of the 64x64 diagonal blocks of lower-triangular L; lane = column of the inverse.
 // The running column lives in LDS ([r][lane], conflict free); L entries are broadcast reads.
 __global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict__ L, int ldl, int N,
@@ -349,21 +590,43 @@ __global__ void set_int_kernel(int* p, int v) { *p = v; }
 
 static int potrf_gen() {
   static int g = -1;
-  if (g < 0) { const char* e = getenv("PPBO_POTRF_GEN"); g = e ? atoi(e) : 2; }
+  if (g < 0) { const char* e = getenv("PPBO_POTRF_GEN"); g = e ? atoi(e) : 3; }
   return g;
 }
 
 int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hipStream_t s) {
   PpboProfScope pf(ctx, ppbo_ctx::PF_POTRF, s);
   set_int_kernel<<<1, 1, 0, s>>>(d_info, 0);
+  const int gen = potrf_gen();
+  const int npanel = (N + NB - 1) / NB;
+  double* diag = nullptr;
+  if (gen >= 3 && npanel > 1) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)panel_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS);
+      (void)hipFuncSetAttribute((const void*)syrk64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS);
+      attr_done = true;
+    }
+    diag = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_POTRF, (size_t)npanel * NB * NB * sizeof(double));
+    if (!diag) return (int)hipErrorOutOfMemory;
+  }
   for (int k0 = 0; k0 < N; k0 += NB) {
     const int kb = (N - k0 < NB) ? (N - k0) : NB;
-    if (potrf_gen() >= 2) potf2_block_kernel<<<1, 256, 0, s>>>(d_A, lda, k0, kb, d_info);
-    else potf2_wave_kernel<<<1, 64, 0, s>>>(d_A, lda, k0, kb, d_info);
     const int rest = N - k0 - NB;
-    if (rest > 0) {
-      if (potrf_gen() >= 2) trsm_mfma_kernel<<<(rest + 63) / 64, 256, 0, s>>>(d_A, lda, N, k0, d_info);
-      else trsm_panel_kernel<<<(rest + 127) / 128, 128, 0, s>>>(d_A, lda, N, k0, d_info);
+    if (gen >= 3 && rest > 0) {
+      panel_fused_kernel<<<(rest + 63) / 64, 256, PANEL_LDS, s>>>(d_A, lda, N, k0, diag + (size_t)(k0 / NB) * NB * NB, d_info);
+    } else {
+      if (gen >= 2) potf2_block_kernel<<<1, 256, 0, s>>>(d_A, lda, k0, kb, d_info);
+      else potf2_wave_kernel<<<1, 64, 0, s>>>(d_A, lda, k0, kb, d_info);
+      if (rest > 0) {
+        if (gen >= 2) trsm_mfma_kernel<<<(rest + 63) / 64, 256, 0, s>>>(d_A, lda, N, k0, d_info);
+        else trsm_panel_kernel<<<(rest + 127) / 128, 128, 0, s>>>(d_A, lda, N, k0, d_info);
+      }
+    }
+    if (rest > 0 && gen >= 3) {
+      const int nt = (rest + NB - 1) / NB;
+      syrk64_kernel<<<dim3(nt + 1, (nt + 1) / 2), 256, SYRK_LDS, s>>>(d_A, lda, N, k0, d_info);
+    } else if (rest > 0) {
       GemmArgs g{};
       g.A = d_A + (size_t)(k0 + NB) * lda + k0; g.lda = lda;
       g.B = g.A; g.ldb = lda;
@@ -373,6 +636,7 @@ int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hi
       if (int rc = ppbo_gemm_launch(ctx, g, 0, 1, s)) return rc;
     }
   }
+  if (diag) scatter_diag_kernel<<<npanel - 1, 256, 0, s>>>(d_A, lda, diag, d_info);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
