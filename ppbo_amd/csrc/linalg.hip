@@ -2,12 +2,15 @@
 //   reference: misc.py:96-100 (pd_inverse = LAPACK posv with B = I), the Cholesky
 //   factorizations inside SciPy's trust-exact (gp_model.py:382-384).
 //
-// potrf (right-looking, NB = 64), per panel:
-//   potf2_wave   one wavefront, lane = row of the 64x64 diagonal block held in 64 fp64
-//                registers; column pivots/multipliers move with v_readlane (no LDS, no barrier)
-//   trsm_panel   one lane per row below the panel: 64-step forward substitution against
-//                the diagonal block broadcast from LDS
-//   syrk         trailing update on the fp64 MFMA engine (gemm.hip, NT form, lower tiles only)
+// potrf (right-looking, NB = 64) is latency-bound at these sizes (2.9 GFLOP at N = 2048), so the design
+// minimises the dependent chain per panel step rather than flops:
+//   default   potrf_step_kernel: ONE launch per step.  Its "panel" workgroups each factor the 64x64
+//             diagonal block themselves (16-column slabs: one wavefront with lane = row and v_readlane
+//             multipliers, MFMA updates between slabs) and solve their 64 rows below it with the block
+//             inverses on the matrix cores; its "update" workgroups apply the PREVIOUS panel's rank-64
+//             update to everything right of the current block column (one step of lookahead).
+//   PPBO_POTRF_GEN=2   three launches per step: potf2_block, trsm_mfma, SYRK on the gemm64 engine
+//             (the simple form; kept as the cross-check for the fused one).
 // trtri: 64x64 diagonal inverses (lane = column), then log2(N/64) levels of batched MFMA GEMMs
 //   X21 = -inv(L22) (L21 inv(L11)).
 // A failing pivot writes its 1-based column to *d_info; later kernels see it and return at once.
@@ -30,76 +33,7 @@ __device__ __forceinline__ double rsqrt_refined(double d) {
   return y;
 }
 
-// One wavefront factors a 64x64 diagonal block: lane = row, the row lives in 64 fp64 registers;
-// pivots and multipliers move between lanes with v_readlane (no LDS, no barrier), the pivot scaling is
-// one refined v_rsq_f64 per column instead of sqrt + divide.  (Publishing the scaled column through
-// LDS and reading it back as broadcast ds_read_b128 was measured SLOWER: 38.5 vs 29.5 us -- a single
-// wavefront exposes the full LDS latency on every column.)
-__global__ __launch_bounds__(64) void potf2_wave_kernel(double* __restrict__ A, int lda, int k0, int kb,
-                                                        int* __restrict__ info) {
-  if (*info != 0) return;
-  const int lane = threadIdx.x;
-  double a[NB];
-  double* row = A + (size_t)(k0 + lane) * lda + k0;
-#pragma unroll
-  for (int c = 0; c < NB; ++c) a[c] = (lane < kb && c < kb && c <= lane) ? row[c] : ((c == lane) ? 1.0 : 0.0);
-  int fail = 0;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const double d = lane_bcast(a[j], j);
-    if (!(d > 0.0) && fail == 0 && j < kb) fail = j + 1;  // also catches NaN
-    const double rs = rsqrt_refined(d);
-    const double lij = (lane == j) ? d * rs : a[j] * rs;
-    a[j] = lij;
-#pragma unroll
-    for (int k = j + 1; k < NB; ++k) {
-      const double lkj = lane_bcast(lij, k);
-      a[k] -= lij * lkj;
-    }
-  }
-  if (fail) {
-    if (lane == 0) *info = k0 + fail;
-    return;
-  }
-  if (lane < kb) {
-#pragma unroll
-    for (int c = 0; c < NB; ++c)
-      if (c <= lane) row[c] = a[c];
-  }
-}
-
-// rows i in [k0+64, N): A[i, k0:k0+64] <- A[i, k0:k0+64] L_kk^-T
-__global__ __launch_bounds__(128) void trsm_panel_kernel(double* __restrict__ A, int lda, int N, int k0,
-                                                         const int* __restrict__ info) {
-  __shared__ __attribute__((aligned(16))) double Ls[NB * NB];
-  __shared__ double Ds[NB];   // reciprocal pivots: the per-column divide becomes a multiply
-  if (*info != 0) return;
-  for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
-    const int r = e / NB, c = e - r * NB;
-    const double v = (c <= r) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;
-    Ls[e] = v;
-    if (r == c) Ds[r] = 1.0 / v;
-  }
-  __syncthreads();
-  const int i = k0 + NB + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  double* row = A + (size_t)i * lda + k0;
-  double x[NB];
-#pragma unroll
-  for (int c = 0; c < NB; ++c) x[c] = row[c];
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    double v = x[c];
-#pragma unroll
-    for (int k = 0; k < c; ++k) v -= x[k] * Ls[c * NB + k];
-    x[c] = v * Ds[c];
-    if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the hoisting of LDS reads (register pressure)
-  }
-#pragma unroll
-  for (int c = 0; c < NB; ++c) row[c] = x[c];
-}
-
-// ---- second-generation panel kernels: blocked by 16 columns so the O(64^3) work runs on the matrix cores
+// ---- panel kernels, blocked by 16 columns so that the O(64^3) work runs on the matrix cores
 constexpr int BLD = NB + 2;   // padded LDS row (doubles): conflict-free MFMA fragment reads
 
 // 64x64 diagonal block, four wavefronts.  For each 16-column slab: wave 0 (lane = row) factors the slab
@@ -252,13 +186,6 @@ __global__ __launch_bounds__(256) void trsm_mfma_kernel(double* __restrict__ A, 
 }
 
 
-// ---- third generation: one kernel per panel.  Every workgroup of the panel launch factors the 64x64
-// diagonal block ITSELF (the same 4-wave blocked factorization as potf2_block, in its own LDS) and then
-// solves its 64 rows below it, so the diagonal factor never travels between workgroups and the
-// potf2 -> trsm kernel boundary (launch gap + ramp, ~5 us of a ~40 us panel step) disappears.  The
-// redundant flops are free: a panel launch has at most N/64 - 1 workgroups on 256 CUs.
-// Nobody may overwrite A_kk while another workgroup can still be reading it, so workgroup 0 writes
-// L_kk to a side buffer (diag_out, one 64x64 slot per panel) that is scattered back once at the end.
 // inverse of the 16x16 lower-triangular diagonal block b of the factored panel block (lane = column c < 16);
 // Rinv holds the reciprocal pivots left by the factorization
 __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, const double* __restrict__ Rinv,
@@ -277,26 +204,114 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
   for (int r = 0; r < 16; ++r) Li[(b * 16 + r) * 18 + c] = y[r];
 }
 
-constexpr int PANEL_LDS = (NB * BLD + 4 * 16 * 18 + 4 * 16 * BLD + NB + 2) * (int)sizeof(double);
+// ---- ONE launch per panel step, with one step of lookahead.
+// Launch k holds two independent kinds of workgroup:
+//   panel part (the first nP workgroups, one per 64 rows below the panel): first applies panel k-1's
+//     rank-64 update to block column k only (its own 64 rows and, redundantly, the diagonal block), then
+//     factors the diagonal block ITSELF -- the factor never travels between workgroups, the redundant
+//     flops are free on <= 31 of 256 CUs -- and solves its 64 rows against it.  Nobody may overwrite A_kk
+//     while another workgroup can still be reading it, so workgroup 0 parks L_kk in a side buffer
+//     (diag_out, one 64x64 slot per panel) that scatter_diag_kernel copies back once at the end;
+//   update part (the remaining workgroups, one per 64x64 tile): panel k-1's trailing update on block
+//     columns >= k+1, i.e. everything the panel part does not touch.
+// Block column k therefore meets panel k-1's update one launch late, inside the panel part, and the
+// bulk trailing update runs in the shadow of the latency-bound panel instead of after it: a step costs
+// max(panel, update) and one launch instead of panel + update and two.  No workgroup reads what another
+// one writes in the same launch: the panel part reads columns k-1 and k and writes column k (the diagonal
+// factor to the side buffer), the update part reads column k-1 and read-modify-writes columns >= k+1.
+// More than half of the CU's 160 KB: exactly one workgroup per CU, so a panel workgroup never shares its SIMDs
+// with MFMA-saturated update workgroups (measured: sharing stretches the panel part from 23.5 to 30.5 us).
+constexpr int STEP_LDS = 82 * 1024;
 
-__global__ __launch_bounds__(256) void panel_fused_kernel(double* __restrict__ A, int lda, int N, int k0,
-                                                          double* __restrict__ diag_out, int* __restrict__ info) {
+__global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A, int lda, int N, int k0, int has_prev,
+                                                         int nP, int ntS, double* __restrict__ diag_out,
+                                                         int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double plds[];
-  double* Ab = plds;                    // [64][BLD]  A_kk -> L_kk
-  double* Li = Ab + NB * BLD;           // [4][16][18] inverses of the 16x16 diagonal blocks
-  double* Xs = Li + 4 * 16 * 18;        // [4 waves][16][BLD]
-  double* Rinv = Xs + 4 * 16 * BLD;     // [64] 1 / l_jj
-  int& s_fail = *reinterpret_cast<int*>(Rinv + NB);   // all LDS in the dynamic region: keeps its base 16-byte aligned
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  // every global read of the kernel is issued up front: the error word, the diagonal block, and this
-  // wavefront's 16 panel rows (needed only after the factorization) -- one memory latency instead of three
   const int info_in = *info;
-  double a11[16];
+  if ((int)blockIdx.x >= nP) {
+    // ------------------------------------------------ update part: C -= P P^T, P = block column k-1
+    // Persistent: gridDim.x - nP workgroups (one per remaining CU) stride over the folded tile list; the
+    // next tile's operands and C values are requested before the current tile's MFMAs, so a tile costs its
+    // 64 MFMAs per wavefront, not a memory round trip.
+    if (info_in != 0) return;
+    double* Pi = plds;
+    double* Pj = plds + NB * BLD;
+    const int kp = k0 - NB, cs = k0 + NB;
+    const int nSW = gridDim.x - nP, total = (ntS + 1) * ((ntS + 1) / 2);
+    double pi[16], pj[16];
+    double4_t accN[4];
+    int ti = 0, tj = 0;
+    bool valid = false;
+    auto fetch = [&](int idx) {
+      const int c = idx % (ntS + 1), tr = idx / (ntS + 1);
+      if (c <= tr) { ti = tr; tj = c; valid = true; }
+      else { ti = ntS - 1 - tr; tj = c - tr - 1; valid = (ti != tr); }
+      const int i0 = cs + ti * NB, j0 = cs + tj * NB;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int e = t + 256 * q, r = e >> 6, cc = e & 63;
+        pi[q] = (valid && i0 + r < N) ? A[(size_t)(i0 + r) * lda + kp + cc] : 0.0;
+        pj[q] = (valid && ti != tj && j0 + r < N) ? A[(size_t)(j0 + r) * lda + kp + cc] : 0.0;
+      }
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gr = i0 + 16 * wave + lk + 4 * r, gc = j0 + 16 * jt + lr;
+          accN[jt][r] = (valid && gr < N && gc < N) ? A[(size_t)gr * lda + gc] : 0.0;
+        }
+    };
+    int cur = blockIdx.x - nP;
+    if (cur < total) fetch(cur);
+    for (; cur < total; cur += nSW) {
+      const bool v_cur = valid, diag_cur = (ti == tj);
+      const int i0 = cs + ti * NB, j0 = cs + tj * NB;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int e = t + 256 * q;
+        Pi[(e >> 6) * BLD + (e & 63)] = pi[q];
+        if (!diag_cur) Pj[(e >> 6) * BLD + (e & 63)] = pj[q];
+      }
+      double4_t acc[4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) acc[jt] = accN[jt];
+      __syncthreads();
+      if (cur + nSW < total) fetch(cur + nSW);
+      if (v_cur) {
+        const double* Pb = diag_cur ? Pi : Pj;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const double av = -Pi[(16 * wave + lr) * BLD + 4 * kk + lk];
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+            acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pb[(16 * jt + lr) * BLD + 4 * kk + lk], acc[jt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int gr = i0 + 16 * wave + lk + 4 * r, gc = j0 + 16 * jt + lr;
+            if (gr < N && gc < N) A[(size_t)gr * lda + gc] = acc[jt][r];
+          }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // -------------------------------------------------- panel part
+  double* Ab = plds;                    // [64][BLD]  A_kk -> L_kk
+  double* Li = Ab + NB * BLD;           // [4][16][18] inverses of the 16x16 diagonal blocks
+  double* Xs = Li + 4 * 16 * 18;        // [4 waves][16][BLD]; before the factorization: L[k, k-1] as [64][BLD]
+  double* Rinv = Xs + 4 * 16 * BLD;     // [64] 1 / l_jj
+  int& s_fail = *reinterpret_cast<int*>(Rinv + NB);
+  const int kb = (N - k0 < NB) ? (N - k0) : NB;
+  double a11[16], lp[16], afr[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int e = t + 256 * q, r = e >> 6, c = e & 63;
-    a11[q] = (c <= r) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;
+    a11[q] = (r < kb && c <= r) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;   // zero is the only 'else' that keeps the loads in flight together
   }
   const int row0 = k0 + NB + (blockIdx.x * 4 + wave) * 16;
   double4_t rowv[4];
@@ -307,23 +322,75 @@ __global__ __launch_bounds__(256) void panel_fused_kernel(double* __restrict__ A
       const int gr = row0 + lk + 4 * r;
       rowv[c][r] = (gr < N) ? A[(size_t)gr * lda + k0 + 16 * c + lr] : 0.0;
     }
+  if (has_prev) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = t + 256 * q, r = e >> 6, c = e & 63;
+      lp[q] = (r < kb) ? A[(size_t)(k0 + r) * lda + (k0 - NB) + c] : 0.0;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      afr[kk] = (row0 + lr < N) ? A[(size_t)(row0 + lr) * lda + (k0 - NB) + 4 * kk + lk] : 0.0;
+  }
   if (info_in != 0) return;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int e = t + 256 * q;
-    Ab[(e >> 6) * BLD + (e & 63)] = a11[q];
+    Ab[(e >> 6) * BLD + (e & 63)] = ((e >> 6) >= kb && (e >> 6) == (e & 63)) ? 1.0 : a11[q];   // identity padding of a partial last block
+    if (has_prev) Xs[(e >> 6) * BLD + (e & 63)] = lp[q];
   }
   if (t == 0) s_fail = 0;
   __syncthreads();
+  if (has_prev) {
+    // panel k-1's update of this workgroup's rows of block column k ...
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const double av = -afr[kk];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        rowv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xs[(16 * c + lr) * BLD + 4 * kk + lk], rowv[c], 0, 0, 0);
+    }
+    // ... and of the diagonal block: its ten lower tiles are dealt 3/3/2/2 over the waves; a wave's tiles
+    // advance together through k so that consecutive MFMAs never share an accumulator (a dependent
+    // fp64 MFMA issues every ~138 cycles, an independent one every 64)
+    {
+      // tiles in (cb, rb >= cb) order: (0,0) (1,0) (2,0) (3,0) (1,1) (2,1) (3,1) (2,2) (3,2) (3,3); wave w owns
+      // entries w, w+4, w+8 (waves 2 and 3 run a discarded copy of the last tile: no branch in the MFMA loop)
+      const int rb0 = wave, cb0 = 0;
+      const int rb1 = (wave < 3) ? wave + 1 : 2, cb1 = (wave < 3) ? 1 : 2;
+      const int rb2 = 3, cb2 = (wave == 0) ? 2 : 3;
+      const int ra0 = (16 * rb0 + lr) * BLD + lk, ca0 = (16 * cb0 + lr) * BLD + lk;
+      const int ra1 = (16 * rb1 + lr) * BLD + lk, ca1 = (16 * cb1 + lr) * BLD + lk;
+      const int ra2 = (16 * rb2 + lr) * BLD + lk, ca2 = (16 * cb2 + lr) * BLD + lk;
+      const int o0 = (16 * rb0 + lk) * BLD + 16 * cb0 + lr;
+      const int o1 = (16 * rb1 + lk) * BLD + 16 * cb1 + lr;
+      const int o2 = (16 * rb2 + lk) * BLD + 16 * cb2 + lr;
+      double4_t d0, d1, d2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d0[r] = Ab[o0 + 4 * r * BLD];
+        d1[r] = Ab[o1 + 4 * r * BLD];
+        d2[r] = Ab[o2 + 4 * r * BLD];
+      }
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra0 + 4 * kk], Xs[ca0 + 4 * kk], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra1 + 4 * kk], Xs[ca1 + 4 * kk], d1, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra2 + 4 * kk], Xs[ca2 + 4 * kk], d2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Ab[o0 + 4 * r * BLD] = d0[r];
+        Ab[o1 + 4 * r * BLD] = d1[r];
+        if (wave < 2) Ab[o2 + 4 * r * BLD] = d2[r];
+      }
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int c0 = 16 * s;
     if (wave == 0) {
-      // left-looking within the slab: column j first collects the contributions of columns k < j -- the
-      // multipliers it needs all sit in ONE lane (row c0+j) and are consumed as they are broadcast.  (Written
-      // right-looking, the compiler sinks every update to its use anyway and then spills the 120 live
-      // broadcasts of a slab from SGPRs to VGPR lanes.)  A lone wavefront retires ~1 instruction per 8
-      // cycles here, so the slab costs its instruction count: ~700 -> 2.3 us.
       double a[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) a[j] = Ab[lane * BLD + c0 + j];
@@ -345,7 +412,6 @@ __global__ __launch_bounds__(256) void panel_fused_kernel(double* __restrict__ A
       }
       if (fail && lane == 0 && s_fail == 0) s_fail = fail;
     } else if (wave == 3 && s > 0) {
-      // inverse of the PREVIOUS slab's 16x16 diagonal block (lane = column) while wave 0 factors this one
       invert_diag16(Ab, Rinv, Li, s - 1, lane);
     }
     __syncthreads();
@@ -417,78 +483,15 @@ __global__ __launch_bounds__(256) void panel_fused_kernel(double* __restrict__ A
   }
 }
 
-
-// Trailing update of one panel step, C -= P P^T with P the freshly solved (rest x 64) panel: one 64x64 tile
-// of the lower triangle per workgroup.  The generic engine streams K in 16-deep stages with one stage of
-// prefetch; at K = 64 that is four dependent memory round trips for 0.5 MFLOP of work.  Here both panel
-// blocks and the C tile are requested at once (one round trip), staged once, and the 64 MFMAs per
-// wavefront run from LDS without further barriers.  Tiles are enumerated by folding the triangle into a
-// (nt+1) x ceil(nt/2) rectangle.
-constexpr int SYRK_LDS = 2 * NB * BLD * (int)sizeof(double);
-
-__global__ __launch_bounds__(256) void syrk64_kernel(double* __restrict__ A, int lda, int N, int k0,
-                                                     const int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double slds[];
-  double* Pi = slds;               // [64][BLD] rows of the panel for the tile's rows
-  double* Pj = slds + NB * BLD;    // [64][BLD] ... for the tile's columns
-  const int rest0 = k0 + NB, rest = N - rest0, nt = (rest + NB - 1) / NB;
-  const int c = blockIdx.x, tr = blockIdx.y;
-  int ti, tj;      // ti >= tj
-  if (c <= tr) { ti = tr; tj = c; }
-  else { ti = nt - 1 - tr; tj = c - tr - 1; if (ti == tr || tj > ti) return; }
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int lr = lane & 15, lk = lane >> 4;
-  const int i0 = rest0 + ti * NB, j0 = rest0 + tj * NB;
-  const int info_in = *info;
-  double pi[16], pj[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int e = t + 256 * q, r = e >> 6, cc = e & 63;
-    pi[q] = (i0 + r < N) ? A[(size_t)(i0 + r) * lda + k0 + cc] : 0.0;
-    pj[q] = (ti != tj && j0 + r < N) ? A[(size_t)(j0 + r) * lda + k0 + cc] : 0.0;
-  }
-  double4_t acc[4];
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int gr = i0 + 16 * wave + lk + 4 * r, gc = j0 + 16 * jt + lr;
-      acc[jt][r] = (gr < N && gc < N) ? A[(size_t)gr * lda + gc] : 0.0;
-    }
-  if (info_in != 0) return;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int e = t + 256 * q;
-    Pi[(e >> 6) * BLD + (e & 63)] = pi[q];
-    if (ti != tj) Pj[(e >> 6) * BLD + (e & 63)] = pj[q];
-  }
-  __syncthreads();
-  const double* Pb = (ti != tj) ? Pj : Pi;
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) {
-    const double av = -Pi[(16 * wave + lr) * BLD + 4 * kk + lk];
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-      acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pb[(16 * jt + lr) * BLD + 4 * kk + lk], acc[jt], 0, 0, 0);
-  }
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int gr = i0 + 16 * wave + lk + 4 * r, gc = j0 + 16 * jt + lr;
-      if (gr < N && gc < N) A[(size_t)gr * lda + gc] = acc[jt][r];
-    }
-}
-
-// diagonal factors parked by panel_fused_kernel -> lower triangles of A's diagonal blocks
-__global__ __launch_bounds__(256) void scatter_diag_kernel(double* __restrict__ A, int lda,
+// diagonal factors parked by potrf_step_kernel -> lower triangles of A's diagonal blocks
+__global__ __launch_bounds__(256) void scatter_diag_kernel(double* __restrict__ A, int lda, int N,
                                                            const double* __restrict__ diag, const int* __restrict__ info) {
   if (*info != 0) return;
   const int k0 = blockIdx.x * NB;
   const double* src = diag + (size_t)blockIdx.x * NB * NB;
   for (int e = threadIdx.x; e < NB * NB; e += 256) {
     const int r = e / NB, c = e - r * NB;
-    if (c <= r) A[(size_t)(k0 + r) * lda + k0 + c] = src[e];
+    if (c <= r && k0 + r < N) A[(size_t)(k0 + r) * lda + k0 + c] = src[e];
   }
 }
 
@@ -588,6 +591,7 @@ __global__ void set_int_kernel(int* p, int v) { *p = v; }
 
 }  // namespace
 
+// 3 (default): potrf_step_kernel; 2: potf2_block + trsm_mfma + gemm64 SYRK
 static int potrf_gen() {
   static int g = -1;
   if (g < 0) { const char* e = getenv("PPBO_POTRF_GEN"); g = e ? atoi(e) : 3; }
@@ -597,36 +601,34 @@ static int potrf_gen() {
 int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hipStream_t s) {
   PpboProfScope pf(ctx, ppbo_ctx::PF_POTRF, s);
   set_int_kernel<<<1, 1, 0, s>>>(d_info, 0);
-  const int gen = potrf_gen();
-  const int npanel = (N + NB - 1) / NB;
-  double* diag = nullptr;
-  if (gen >= 3 && npanel > 1) {
+  if (potrf_gen() >= 3) {
     static bool attr_done = false;
     if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)panel_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS);
-      (void)hipFuncSetAttribute((const void*)syrk64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SYRK_LDS);
+      (void)hipFuncSetAttribute((const void*)potrf_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
       attr_done = true;
     }
-    diag = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_POTRF, (size_t)npanel * NB * NB * sizeof(double));
+    const int npanel = (N + NB - 1) / NB;
+    double* diag = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_POTRF, (size_t)npanel * NB * NB * sizeof(double));
     if (!diag) return (int)hipErrorOutOfMemory;
+    for (int k0 = 0; k0 < N; k0 += NB) {
+      const int rest = N - k0 - NB;
+      const int nP = rest > 0 ? (rest + NB - 1) / NB : 1;
+      const int ntS = (k0 > 0 && rest > 0) ? (rest + NB - 1) / NB : 0;
+      const int nS = ntS ? (ntS + 1) * ((ntS + 1) / 2) : 0;
+      const int nSW = nS < 256 - nP ? nS : 256 - nP;   // one workgroup per CU (STEP_LDS), the update part is persistent
+      potrf_step_kernel<<<nP + nSW, 256, STEP_LDS, s>>>(d_A, lda, N, k0, k0 > 0 ? 1 : 0, nP, ntS,
+                                                        diag + (size_t)(k0 / NB) * NB * NB, d_info);
+    }
+    scatter_diag_kernel<<<npanel, 256, 0, s>>>(d_A, lda, N, diag, d_info);
+    PPBO_LAUNCH_CHECK(ctx);
+    return 0;
   }
   for (int k0 = 0; k0 < N; k0 += NB) {
     const int kb = (N - k0 < NB) ? (N - k0) : NB;
     const int rest = N - k0 - NB;
-    if (gen >= 3 && rest > 0) {
-      panel_fused_kernel<<<(rest + 63) / 64, 256, PANEL_LDS, s>>>(d_A, lda, N, k0, diag + (size_t)(k0 / NB) * NB * NB, d_info);
-    } else {
-      if (gen >= 2) potf2_block_kernel<<<1, 256, 0, s>>>(d_A, lda, k0, kb, d_info);
-      else potf2_wave_kernel<<<1, 64, 0, s>>>(d_A, lda, k0, kb, d_info);
-      if (rest > 0) {
-        if (gen >= 2) trsm_mfma_kernel<<<(rest + 63) / 64, 256, 0, s>>>(d_A, lda, N, k0, d_info);
-        else trsm_panel_kernel<<<(rest + 127) / 128, 128, 0, s>>>(d_A, lda, N, k0, d_info);
-      }
-    }
-    if (rest > 0 && gen >= 3) {
-      const int nt = (rest + NB - 1) / NB;
-      syrk64_kernel<<<dim3(nt + 1, (nt + 1) / 2), 256, SYRK_LDS, s>>>(d_A, lda, N, k0, d_info);
-    } else if (rest > 0) {
+    potf2_block_kernel<<<1, 256, 0, s>>>(d_A, lda, k0, kb, d_info);
+    if (rest > 0) {
+      trsm_mfma_kernel<<<(rest + 63) / 64, 256, 0, s>>>(d_A, lda, N, k0, d_info);
       GemmArgs g{};
       g.A = d_A + (size_t)(k0 + NB) * lda + k0; g.lda = lda;
       g.B = g.A; g.ldb = lda;
@@ -636,7 +638,6 @@ int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hi
       if (int rc = ppbo_gemm_launch(ctx, g, 0, 1, s)) return rc;
     }
   }
-  if (diag) scatter_diag_kernel<<<npanel - 1, 256, 0, s>>>(d_A, lda, diag, d_info);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
