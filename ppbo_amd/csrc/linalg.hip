@@ -186,30 +186,56 @@ __global__ __launch_bounds__(256) void trsm_mfma_kernel(double* __restrict__ A, 
 }
 
 
-// inverse of the 16x16 lower-triangular diagonal block b of the factored panel block (lane = column c < 16);
-// Rinv holds the reciprocal pivots left by the factorization
+// inverse of the 16x16 lower-triangular diagonal block b of the factored panel block, by one level of
+// recursion so that the longest dependent FMA chain is 28 + 8 + 8 instead of 120 (the last block's inverse
+// sits on the panel's critical path).  Lanes 0-7 / 8-15: column (lane & 7) of the inverse of the leading /
+// trailing 8x8 triangle; then lanes 0-7: their column of X21 = -inv(L22) (L21 inv(L11)).
+// Rinv holds the reciprocal pivots left by the factorization.
 __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, const double* __restrict__ Rinv,
                                               double* __restrict__ Li, int b, int lane) {
   if (lane >= 16) return;
-  const int c = lane, c0 = 16 * b;
-  double y[16];
+  const int h = lane >> 3, cc = lane & 7, c0 = 16 * b, o = c0 + 8 * h;
+  double y[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    double v = (r == c) ? 1.0 : 0.0;
+  for (int r = 0; r < 8; ++r) {
+    double v = (r == cc) ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < r; ++k) v -= Ab[(c0 + r) * BLD + c0 + k] * y[k];
-    y[r] = (r >= c) ? v * Rinv[c0 + r] : 0.0;
+    for (int k = 0; k < r; ++k) v -= Ab[(o + r) * BLD + o + k] * y[k];
+    y[r] = (r >= cc) ? v * Rinv[o + r] : 0.0;
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) Li[(b * 16 + r) * 18 + c] = y[r];
+  for (int r = 0; r < 8; ++r) {
+    Li[(b * 16 + 8 * h + r) * 18 + 8 * h + cc] = y[r];
+    if (h == 1) Li[(b * 16 + r) * 18 + 8 + cc] = 0.0;      // the block above the diagonal
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (h == 0) {
+    double tv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += Ab[(c0 + 8 + r) * BLD + c0 + k] * y[k];
+      tv[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      double v = 0.0;
+#pragma unroll
+      for (int j = 0; j <= r; ++j) v -= Li[(b * 16 + 8 + r) * 18 + 8 + j] * tv[j];
+      Li[(b * 16 + 8 + r) * 18 + cc] = v;
+    }
+  }
 }
 
 // ---- ONE launch per panel step, with one step of lookahead.
 // Launch k holds two independent kinds of workgroup:
-//   panel part (the first nP workgroups, one per 64 rows below the panel): first applies panel k-1's
+//   panel part (the first nP workgroups, one per 48 rows below the panel): first applies panel k-1's
 //     rank-64 update to block column k only (its own 64 rows and, redundantly, the diagonal block), then
 //     factors the diagonal block ITSELF -- the factor never travels between workgroups, the redundant
-//     flops are free on <= 31 of 256 CUs -- and solves its 64 rows against it.  Nobody may overwrite A_kk
+//     flops are free on <= 42 of 256 CUs -- and solves its 48 rows against it.  Nobody may overwrite A_kk
 //     while another workgroup can still be reading it, so workgroup 0 parks L_kk in a side buffer
 //     (diag_out, one 64x64 slot per panel) that scatter_diag_kernel copies back once at the end;
 //   update part (the remaining workgroups, one per 64x64 tile): panel k-1's trailing update on block
@@ -301,20 +327,39 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
     return;
   }
   // -------------------------------------------------- panel part
+  // Wave 0 only factors; waves 1-3 own 16 panel rows each (48 rows per workgroup) and fill the time wave 0
+  // spends inside a slab (~2.2 us, waves 1-3 would otherwise idle at the barrier):
+  //   during slab 0   panel k-1's update of their own rows
+  //   during slab s   wave 3 inverts diagonal block s-1; waves 1-3 solve column block s-2 of their rows
+  // so that after the last slab only two column blocks and one 16x16 inverse remain.
   double* Ab = plds;                    // [64][BLD]  A_kk -> L_kk
   double* Li = Ab + NB * BLD;           // [4][16][18] inverses of the 16x16 diagonal blocks
-  double* Xs = Li + 4 * 16 * 18;        // [4 waves][16][BLD]; before the factorization: L[k, k-1] as [64][BLD]
+  double* Xs = Li + 4 * 16 * 18;        // [4 waves][16][BLD] solve staging; until slab 0 is done: L[k, k-1] as [64][BLD]
   double* Rinv = Xs + 4 * 16 * BLD;     // [64] 1 / l_jj
   int& s_fail = *reinterpret_cast<int*>(Rinv + NB);
   const int kb = (N - k0 < NB) ? (N - k0) : NB;
+  // global reads, most urgent first (the counter retires them in order): diagonal block and L[k, k-1]
+  // gate the factorization, the wave's own rows are not needed before slab 0 is under way
   double a11[16], lp[16], afr[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int e = t + 256 * q, r = e >> 6, c = e & 63;
     a11[q] = (r < kb && c <= r) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;   // zero is the only 'else' that keeps the loads in flight together
   }
-  const int row0 = k0 + NB + (blockIdx.x * 4 + wave) * 16;
+  if (has_prev) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = t + 256 * q, r = e >> 6, c = e & 63;
+      lp[q] = (r < kb) ? A[(size_t)(k0 + r) * lda + (k0 - NB) + c] : 0.0;
+    }
+  }
+  const int row0 = (wave == 0) ? N : k0 + NB + (blockIdx.x * 3 + wave - 1) * 16;
   double4_t rowv[4];
+  if (has_prev) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      afr[kk] = (row0 + lr < N) ? A[(size_t)(row0 + lr) * lda + (k0 - NB) + 4 * kk + lk] : 0.0;
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -322,16 +367,6 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
       const int gr = row0 + lk + 4 * r;
       rowv[c][r] = (gr < N) ? A[(size_t)gr * lda + k0 + 16 * c + lr] : 0.0;
     }
-  if (has_prev) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int e = t + 256 * q, r = e >> 6, c = e & 63;
-      lp[q] = (r < kb) ? A[(size_t)(k0 + r) * lda + (k0 - NB) + c] : 0.0;
-    }
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
-      afr[kk] = (row0 + lr < N) ? A[(size_t)(row0 + lr) * lda + (k0 - NB) + 4 * kk + lk] : 0.0;
-  }
   if (info_in != 0) return;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
@@ -342,115 +377,44 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
   if (t == 0) s_fail = 0;
   __syncthreads();
   if (has_prev) {
-    // panel k-1's update of this workgroup's rows of block column k ...
+    // panel k-1's update of the diagonal block: its ten lower tiles are dealt 3/3/2/2 over the waves; a wave's
+    // tiles advance together through k so that consecutive MFMAs never share an accumulator (a dependent
+    // fp64 MFMA issues every ~138 cycles, an independent one every 64)
+    // tiles in (cb, rb >= cb) order: (0,0) (1,0) (2,0) (3,0) (1,1) (2,1) (3,1) (2,2) (3,2) (3,3); wave w owns
+    // entries w, w+4, w+8 (waves 2 and 3 run a discarded copy of the last tile: no branch in the MFMA loop)
+    const int rb0 = wave, cb0 = 0;
+    const int rb1 = (wave < 3) ? wave + 1 : 2, cb1 = (wave < 3) ? 1 : 2;
+    const int rb2 = 3, cb2 = (wave == 0) ? 2 : 3;
+    const int ra0 = (16 * rb0 + lr) * BLD + lk, ca0 = (16 * cb0 + lr) * BLD + lk;
+    const int ra1 = (16 * rb1 + lr) * BLD + lk, ca1 = (16 * cb1 + lr) * BLD + lk;
+    const int ra2 = (16 * rb2 + lr) * BLD + lk, ca2 = (16 * cb2 + lr) * BLD + lk;
+    const int o0 = (16 * rb0 + lk) * BLD + 16 * cb0 + lr;
+    const int o1 = (16 * rb1 + lk) * BLD + 16 * cb1 + lr;
+    const int o2 = (16 * rb2 + lk) * BLD + 16 * cb2 + lr;
+    double4_t d0, d1, d2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d0[r] = Ab[o0 + 4 * r * BLD];
+      d1[r] = Ab[o1 + 4 * r * BLD];
+      d2[r] = Ab[o2 + 4 * r * BLD];
+    }
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-      const double av = -afr[kk];
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        rowv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xs[(16 * c + lr) * BLD + 4 * kk + lk], rowv[c], 0, 0, 0);
+      d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra0 + 4 * kk], Xs[ca0 + 4 * kk], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra1 + 4 * kk], Xs[ca1 + 4 * kk], d1, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra2 + 4 * kk], Xs[ca2 + 4 * kk], d2, 0, 0, 0);
     }
-    // ... and of the diagonal block: its ten lower tiles are dealt 3/3/2/2 over the waves; a wave's tiles
-    // advance together through k so that consecutive MFMAs never share an accumulator (a dependent
-    // fp64 MFMA issues every ~138 cycles, an independent one every 64)
-    {
-      // tiles in (cb, rb >= cb) order: (0,0) (1,0) (2,0) (3,0) (1,1) (2,1) (3,1) (2,2) (3,2) (3,3); wave w owns
-      // entries w, w+4, w+8 (waves 2 and 3 run a discarded copy of the last tile: no branch in the MFMA loop)
-      const int rb0 = wave, cb0 = 0;
-      const int rb1 = (wave < 3) ? wave + 1 : 2, cb1 = (wave < 3) ? 1 : 2;
-      const int rb2 = 3, cb2 = (wave == 0) ? 2 : 3;
-      const int ra0 = (16 * rb0 + lr) * BLD + lk, ca0 = (16 * cb0 + lr) * BLD + lk;
-      const int ra1 = (16 * rb1 + lr) * BLD + lk, ca1 = (16 * cb1 + lr) * BLD + lk;
-      const int ra2 = (16 * rb2 + lr) * BLD + lk, ca2 = (16 * cb2 + lr) * BLD + lk;
-      const int o0 = (16 * rb0 + lk) * BLD + 16 * cb0 + lr;
-      const int o1 = (16 * rb1 + lk) * BLD + 16 * cb1 + lr;
-      const int o2 = (16 * rb2 + lk) * BLD + 16 * cb2 + lr;
-      double4_t d0, d1, d2;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        d0[r] = Ab[o0 + 4 * r * BLD];
-        d1[r] = Ab[o1 + 4 * r * BLD];
-        d2[r] = Ab[o2 + 4 * r * BLD];
-      }
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra0 + 4 * kk], Xs[ca0 + 4 * kk], d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra1 + 4 * kk], Xs[ca1 + 4 * kk], d1, 0, 0, 0);
-        d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra2 + 4 * kk], Xs[ca2 + 4 * kk], d2, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        Ab[o0 + 4 * r * BLD] = d0[r];
-        Ab[o1 + 4 * r * BLD] = d1[r];
-        if (wave < 2) Ab[o2 + 4 * r * BLD] = d2[r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      Ab[o0 + 4 * r * BLD] = d0[r];
+      Ab[o1 + 4 * r * BLD] = d1[r];
+      if (wave < 2) Ab[o2 + 4 * r * BLD] = d2[r];
     }
     __syncthreads();
   }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int c0 = 16 * s;
-    if (wave == 0) {
-      double a[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) a[j] = Ab[lane * BLD + c0 + j];
-      int fail = 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double v = a[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) v -= a[k] * lane_bcast(a[k], c0 + j);
-        const double d = lane_bcast(v, c0 + j);
-        if (!(d > 0.0) && fail == 0) fail = c0 + j + 1;
-        const double rs = rsqrt_refined(d);
-        a[j] = (lane == c0 + j) ? d * rs : v * rs;
-        if (lane == c0 + j) Rinv[c0 + j] = rs;
-      }
-      if (lane >= c0) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) Ab[lane * BLD + c0 + j] = (c0 + j <= lane) ? a[j] : 0.0;
-      }
-      if (fail && lane == 0 && s_fail == 0) s_fail = fail;
-    } else if (wave == 3 && s > 0) {
-      invert_diag16(Ab, Rinv, Li, s - 1, lane);
-    }
-    __syncthreads();
-    if (s_fail) break;
-    int tile = 0;
-#pragma unroll
-    for (int cb = 1; cb < 4; ++cb) {
-#pragma unroll
-      for (int rb = 1; rb < 4; ++rb) {
-        if (cb <= s || rb < cb) continue;
-        if ((tile++ & 3) != wave) continue;
-        double4_t acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = Ab[(16 * rb + lk + 4 * r) * BLD + 16 * cb + lr];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const double av = -Ab[(16 * rb + lr) * BLD + c0 + kk * 4 + lk];
-          const double bv = Ab[(16 * cb + lr) * BLD + c0 + kk * 4 + lk];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Ab[(16 * rb + lk + 4 * r) * BLD + 16 * cb + lr] = acc[r];
-      }
-    }
-    if (s < 3) __syncthreads();
-  }
-  if (!s_fail && wave == 0) invert_diag16(Ab, Rinv, Li, 3, lane);
-  __syncthreads();
-  if (s_fail) {
-    if (blockIdx.x == 0 && t == 0) *info = k0 + s_fail;
-    return;
-  }
-  if (blockIdx.x == 0) {
-    for (int e = t; e < NB * NB; e += 256) diag_out[e] = Ab[(e >> 6) * BLD + (e & 63)];
-  }
-  if (row0 >= N) return;
   double* xs = Xs + wave * 16 * BLD;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
+  // column block c of this wave's rows: X_c = (R_c - sum_{p<c} X_p L_cp^T) inv(L_cc)^T
+  auto solve_block = [&](int c) {
     double4_t acc = rowv[c];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -480,7 +444,94 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
       if (gr < N) A[(size_t)gr * lda + k0 + 16 * c + lr] = x[r];
     }
     __builtin_amdgcn_wave_barrier();
+  };
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int c0 = 16 * s;
+    if (wave == 0) {
+      // left-looking within the slab: column j first collects the contributions of columns k < j -- the
+      // multipliers it needs all sit in ONE lane (row c0+j) and are consumed as they are broadcast.  (Written
+      // right-looking, the compiler sinks every update to its use anyway and then spills the 120 live
+      // broadcasts of a slab from SGPRs to VGPR lanes.)  A lone wavefront retires ~1 instruction per 8
+      // cycles here, so the slab costs its instruction count; hence no select for the pivot lane
+      // (its v IS d, so v * rs = sqrt(d)) and one reciprocal-pivot store per slab instead of per column.
+      double a[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a[j] = Ab[lane * BLD + c0 + j];
+      int fail = 0;
+      double rsv = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double v = a[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v -= a[k] * lane_bcast(a[k], c0 + j);
+        const double d = lane_bcast(v, c0 + j);
+        if (!(d > 0.0) && fail == 0) fail = c0 + j + 1;
+        const double rs = rsqrt_refined(d);
+        a[j] = v * rs;
+        rsv = (lane == c0 + j) ? rs : rsv;
+      }
+      if (lane >= c0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Ab[lane * BLD + c0 + j] = (c0 + j <= lane) ? a[j] : 0.0;
+        if (lane < c0 + 16) Rinv[lane] = rsv;
+      }
+      if (fail && lane == 0 && s_fail == 0) s_fail = fail;
+    } else {
+      if (s == 0 && has_prev) {
+        // panel k-1's update of this wave's rows of block column k (L[k, k-1] is still staged in Xs)
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const double av = -afr[kk];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            rowv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xs[(16 * c + lr) * BLD + 4 * kk + lk], rowv[c], 0, 0, 0);
+        }
+      }
+      if (s >= 1 && wave == 3) invert_diag16(Ab, Rinv, Li, s - 1, lane);
+      if (s >= 2 && row0 < N) solve_block(s - 2);
+    }
+    __syncthreads();
+    if (s_fail) break;
+    int tile = 0;
+#pragma unroll
+    for (int cb = 1; cb < 4; ++cb) {
+#pragma unroll
+      for (int rb = 1; rb < 4; ++rb) {
+        if (cb <= s || rb < cb) continue;
+        if ((tile++ & 3) != wave) continue;
+        double4_t acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Ab[(16 * rb + lk + 4 * r) * BLD + 16 * cb + lr];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const double av = -Ab[(16 * rb + lr) * BLD + c0 + kk * 4 + lk];
+          const double bv = Ab[(16 * cb + lr) * BLD + c0 + kk * 4 + lk];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ab[(16 * rb + lk + 4 * r) * BLD + 16 * cb + lr] = acc[r];
+      }
+    }
+    if (s < 3) __syncthreads();
   }
+  if (!s_fail) {
+    if (wave == 0) invert_diag16(Ab, Rinv, Li, 3, lane);
+    else if (row0 < N) solve_block(2);
+  }
+  __syncthreads();
+  if (s_fail) {
+    if (blockIdx.x == 0 && t == 0) *info = k0 + s_fail;
+    return;
+  }
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = t + 256 * q;
+      diag_out[e] = Ab[(e >> 6) * BLD + (e & 63)];
+    }
+  }
+  if (row0 < N) solve_block(3);
 }
 
 // diagonal factors parked by potrf_step_kernel -> lower triangles of A's diagonal blocks
@@ -612,7 +663,7 @@ int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hi
     if (!diag) return (int)hipErrorOutOfMemory;
     for (int k0 = 0; k0 < N; k0 += NB) {
       const int rest = N - k0 - NB;
-      const int nP = rest > 0 ? (rest + NB - 1) / NB : 1;
+      const int nP = rest > 0 ? (rest + 47) / 48 : 1;   // panel part: 3 row-owning wavefronts of 16 rows
       const int ntS = (k0 > 0 && rest > 0) ? (rest + NB - 1) / NB : 0;
       const int nS = ntS ? (ntS + 1) * ((ntS + 1) / 2) : 0;
       const int nSW = nS < 256 - nP ? nS : 256 - nP;   // one workgroup per CU (STEP_LDS), the update part is persistent
