@@ -157,6 +157,15 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
 int ppbo_predict_cov(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int M,
                      double shrink, double* d_mu, double* d_cov, void* stream);
 
+/* ---- f-2: posterior mean with its analytic gradient ----------------------------
+ * d_mu[M] = K*^T alpha (src/gp_model.py:454-458), d_grad[M,D] = d mu / d x in the model's scaled
+ * coordinates.  The reference has no gradient: mu_star (src/gp_model.py:415-437) maximises mu_pred by
+ * differential evolution; the drop-in refines the best candidates of the batched search by a
+ * multi-start ascent on these gradients instead.  Only kernel_id, N, D, theta, d_X, d_alpha of the
+ * model are read. */
+int ppbo_mean_grad(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
+                   double* d_mu, double* d_grad, void* stream);
+
 /* ---- K10: Monte-Carlo line acquisition -------------------------------------
  * replaces EI / varmax (src/acquisition.py:72-81, 170-178) for B lines of G points
  * with stored standard-normal draws d_z[S,G]: f = mu + chol(cov) z.

@@ -389,6 +389,29 @@ def predict_mean_var(Xc, X, theta, alpha, A, kernel="SE_kernel"):
     return mu, var
 
 
+def mean_grad(Xc, X, theta, alpha, kernel="SE_kernel"):
+    """mu = K*' alpha and its gradient with respect to the (scaled) point.  The reference has no
+    gradient function (mu_star maximises mu_pred by differential evolution, src/gp_model.py:415-437);
+    this is the derivative of the kernels of src/kernels.py:19-53, pinned in the tests by central
+    differences of the pinned mu."""
+    Xc = np.atleast_2d(np.asarray(Xc, dtype=np.float64))
+    l, sf = theta[1], theta[2]
+    K = KERNELS[kernel](Xc, X, theta)                       # [M, N]
+    W = K * alpha[None, :]
+    mu = W.sum(axis=1)
+    diff = Xc[:, None, :] - X[None, :, :]                   # [M, N, D]
+    if kernel == "SE_kernel":
+        g = -np.einsum("mn,mnd->md", W, diff) / l ** 2
+    elif kernel == "RQ_kernel":
+        r2 = np.einsum("mnd,mnd->mn", diff, diff)
+        g = -np.einsum("mn,mnd->md", W / (1.0 + r2 / (4.0 * l ** 2)), diff) / l ** 2
+    else:
+        fac = -(2.0 * np.pi / l ** 2) * np.sin(2.0 * np.pi * diff)
+        fac[:, :, 2] = -diff[:, :, 2] / (l + 0.05) ** 2
+        g = np.einsum("mn,mnd->md", W, fac)
+    return mu, g
+
+
 def pointwise_ei(mu, var, mustar):
     """G=1 closed form of the EI Monte Carlo (src/acquisition.py:72-81):
     E[max(f - mustar, 0)], f ~ N(mu, var)."""

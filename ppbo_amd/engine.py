@@ -268,6 +268,16 @@ class Engine:
         self._check(rc, "ppbo_predict_cov")
         return mu, cov
 
+    def mean_grad(self, post: Posterior, Xc):
+        """mu[M] and d mu / d x [M,D] at the rows of Xc (ppbo_mean_grad)."""
+        Xc = self.dev(Xc)
+        M, D = Xc.shape
+        md = self._model(post, False)
+        mu, grad = self.empty(M), self.empty(M, D)
+        rc = self.lib.ppbo_mean_grad(self.ctx, C.byref(md), _ptr(Xc), M, _ptr(mu), _ptr(grad), self._stream())
+        self._check(rc, "ppbo_mean_grad")
+        return mu, grad
+
     def line_acq(self, post: Posterior, grid, z, mustar, shrink=SHRINKAGE, jitter=0.0):
         grid = self.dev(grid)
         B, G, _ = grid.shape

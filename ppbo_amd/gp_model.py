@@ -25,8 +25,8 @@ from .engine import NotPositiveDefinite, SCORE_MEAN, get_engine
 from .feedback_processing import FeedbackProcessing
 
 SEARCH_CANDIDATES = 65536      # uniform candidates per mu_star trial
-ZOOM_CANDIDATES = 8192         # candidates per local zoom stage
-ZOOM_RADII = (0.15, 0.05, 0.015, 0.005)
+ASCENT_STARTS = 32             # best well-separated candidates refined together on the device
+ASCENT_ITERS = 100             # cap on batched ascent iterations (one ppbo_mean_grad launch each)
 
 
 class GPModel:
@@ -376,27 +376,50 @@ class GPModel:
         return out["mu"].cpu().numpy()
 
     # ------------------------------------------------------------------ maximiser of the posterior mean
-    def _argmax_mean(self, cand):
-        out = self.eng.predict(self._mean_post(), cand, score=SCORE_MEAN, want_mu=False, want_var=False)
-        return out["best_val"], out["best_idx"]
+    def _ascend(self, starts):
+        """Batched projected gradient ascent on the posterior mean from K starts at once: Barzilai-Borwein
+        step lengths per start, monotone safeguard (a start only moves when mu does not drop), one
+        ppbo_mean_grad launch for all starts per iteration.  SURVEY 8(f) f-2."""
+        post = self._mean_post()
+        x = np.clip(np.atleast_2d(starts).astype(float), 0.0, 1.0)
+        mu_t, g_t = self.eng.mean_grad(post, x)
+        mu, g = mu_t.cpu().numpy(), g_t.cpu().numpy()
+        gn = np.linalg.norm(g, axis=1)
+        step = 0.02 / np.maximum(gn, 1e-300)                  # first move: 0.02 in the unit box
+        for _ in range(ASCENT_ITERS):
+            pg = np.where(((x <= 0.0) & (g < 0.0)) | ((x >= 1.0) & (g > 0.0)), 0.0, g)
+            if np.max(np.linalg.norm(pg, axis=1) * step) < 1e-9:
+                break
+            xn = np.clip(x + step[:, None] * pg, 0.0, 1.0)
+            mun_t, gn_t = self.eng.mean_grad(post, xn)
+            mun, gnew = mun_t.cpu().numpy(), gn_t.cpu().numpy()
+            ok = mun >= mu
+            sv, yv = xn - x, gnew - g
+            curv = -(sv * yv).sum(axis=1)                     # > 0 where mu is locally concave along the move
+            bb = (sv * sv).sum(axis=1) / np.maximum(curv, 1e-300)
+            step = np.where(ok, np.where(curv > 0.0, bb, 2.0 * step), 0.25 * step)
+            x = np.where(ok[:, None], xn, x)
+            g = np.where(ok[:, None], gnew, g)
+            mu = np.where(ok, mun, mu)
+        return x, mu
 
     def _polish(self, x0):
-        """Bounded quasi-Newton polish; value and central-difference gradient of every iterate
-        come from ONE batched device evaluation of 2D+1 points."""
-        D, h = self.D, 1e-5
+        """Bounded quasi-Newton polish of one point with the analytic device gradient."""
+        post = self._mean_post()
 
         def fg(x):
-            P = np.repeat(x[None, :], 2 * D + 1, axis=0)
-            P[1:D + 1] += h * np.eye(D)
-            P[D + 1:] -= h * np.eye(D)
-            mu = self.mu_pred_batch(np.clip(P, 0.0, 1.0))
-            return -mu[0], -(mu[1:D + 1] - mu[D + 1:]) / (2 * h)
+            mu, g = self.eng.mean_grad(post, np.clip(x, 0.0, 1.0)[None, :])
+            return -float(mu.cpu().numpy()[0]), -g.cpu().numpy()[0]
 
         res = scipy.optimize.minimize(fg, x0, jac=True, method="L-BFGS-B", bounds=self.bounds,
-                                      options={"maxiter": 200})
+                                      options={"maxiter": 200, "ftol": 1e-15, "gtol": 1e-10})
         return np.clip(res.x, 0.0, 1.0), -float(res.fun)
 
     def mu_star(self, mustar_finding_trials=None):
+        """argmax of the posterior mean (gp_model.py:415-437).  The reference runs SciPy differential
+        evolution `trials` times; here every trial scores 65536 candidates in one launch, refines the
+        ASCENT_STARTS best well-separated ones together by gradient ascent on the device, and polishes the
+        winner.  All distinct converged maxima feed xstars_local (gp_model.py:430-431)."""
         trials = self.mustar_finding_trials if mustar_finding_trials is None else mustar_finding_trials
         D = self.D
         found = []
@@ -407,18 +430,20 @@ class GPModel:
                 cand[:k] = self.X[np.random.permutation(self.N)[:k]]      # the design points themselves
                 if self.xstar is not None:
                     cand[k] = self.xstar
-            val, idx = self._argmax_mean(cand)
-            x = cand[idx].copy()
-            for r in ZOOM_RADII:
-                loc = np.clip(x + r * (2.0 * np.random.uniform(size=(ZOOM_CANDIDATES, D)) - 1.0), 0.0, 1.0)
-                loc[0] = x
-                v2, i2 = self._argmax_mean(loc)
-                if v2 >= val:
-                    val, x = v2, loc[i2].copy()
-            xp, vp = self._polish(x)
-            if vp >= val:
-                x, val = xp, vp
-            found.append((val, x))
+            mu_c = self.mu_pred_batch(cand)
+            order = np.argsort(-mu_c)[:4096]
+            starts = []
+            for i in order:                                               # greedy: best first, > 0.05 apart
+                if all(np.linalg.norm(cand[i] - y) > 5e-2 for y in starts):
+                    starts.append(cand[i])
+                    if len(starts) == ASCENT_STARTS:
+                        break
+            xs, vals = self._ascend(np.vstack(starts))
+            best = int(np.argmax(vals))
+            xp, vp = self._polish(xs[best])
+            if vp >= vals[best]:
+                xs[best], vals[best] = xp, vp
+            found.extend(zip(vals.tolist(), xs))
         found.sort(key=lambda p: -p[0])
         xstar = found[0][1].copy()
         local = [found[0][1]]

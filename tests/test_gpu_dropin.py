@@ -74,6 +74,15 @@ def test_mu_star_finds_the_posterior_mean_maximum(golden, name):
     assert mustar >= gp.mu_pred_batch(probe).max() - 1e-12
     assert mustar >= float(np.max(g["mu"]))
     assert abs(mustar - gp.mu_pred(xstar)) < 1e-12
+    # stationarity: the projected analytic gradient vanishes at every reported maximum, and the
+    # reported maxima are distinct by the reference's 0.1 rule (gp_model.py:430-431)
+    _, grad = gp.eng.mean_grad(gp._mean_post(), local)
+    grad = grad.cpu().numpy()
+    pg = np.where(((local <= 0) & (grad < 0)) | ((local >= 1) & (grad > 0)), 0.0, grad)
+    assert np.abs(pg[0]).max() < 1e-5 * max(1.0, abs(mustar))
+    for i in range(len(local)):
+        for j in range(i):
+            assert np.linalg.norm(local[i] - local[j]) > 0.1
 
 
 def _six_hump(v):

@@ -207,6 +207,31 @@ def test_posterior_covariance_vs_reference(eng, golden, name):
 
 
 @pytest.mark.parametrize("name", FITTED)
+def test_mean_grad_vs_oracle(eng, golden, name):
+    """ppbo_mean_grad: mu against the reference's golden means, the gradient against the oracle's analytic
+    derivative (itself pinned by central differences in the CPU suite)."""
+    g = golden(name)
+    post, _ = _posterior(eng, g)
+    Xc = g["Xc"][:96]
+    mu, grad = eng.mean_grad(post, Xc)
+    mu0, grad0 = orc.mean_grad(Xc, g["X"], g["theta"], host(post.alpha), str(g["kernel"]))
+    assert rel(host(mu), mu0) < 1e-9
+    assert rel(host(mu), g["mu"][:96]) < 1e-5
+    assert np.abs(host(grad) - grad0).max() <= 1e-9 * max(np.abs(grad0).max(), 1e-300)
+
+
+def test_mean_grad_ragged_and_errors(eng, golden):
+    g = golden("smoke")
+    post, _ = _posterior(eng, g)
+    mu, grad = eng.mean_grad(post, g["Xc"][:1])
+    assert mu.shape == (1,) and grad.shape == (1, int(g["D"]))
+    mu0, grad0 = orc.mean_grad(g["Xc"][:1], g["X"], g["theta"], host(post.alpha), str(g["kernel"]))
+    assert rel(host(grad), grad0) < 1e-9
+    import ctypes as C
+    assert eng.lib.ppbo_mean_grad(eng.ctx, None, None, 1, None, None, None) < 0
+
+
+@pytest.mark.parametrize("name", FITTED)
 def test_predict_cov_line_vs_reference(eng, golden, name):
     g = golden(name)
     post, _ = _posterior(eng, g)

@@ -136,6 +136,27 @@ def test_prediction(golden, name):
     assert rel(one, g["mu_pred16"]) < 1e-7
 
 
+@pytest.mark.parametrize("name", [n for n in ("smoke", "rq", "cam_small") if n in ALL])
+def test_mean_gradient_is_the_derivative_of_the_pinned_mean(golden, name):
+    """The reference has no gradient; the oracle's analytic one is pinned by central differences of
+    mu = K*' alpha, which test_prediction pins against the reference."""
+    g = golden(name)
+    kern = str(g["kernel"])
+    Xc = g["Xc"][:24]
+    mu, grad = orc.mean_grad(Xc, g["X"], g["theta"], g["alpha"], kern)
+    assert rel(mu, g["mu"][:24]) < 1e-7
+    h = 1e-6
+    D = Xc.shape[1]
+    fd = np.zeros_like(grad)
+    for d in range(D):
+        e = np.zeros(D); e[d] = h
+        fd[:, d] = (orc.mean_grad(Xc + e, g["X"], g["theta"], g["alpha"], kern)[0]
+                    - orc.mean_grad(Xc - e, g["X"], g["theta"], g["alpha"], kern)[0]) / (2 * h)
+    # alpha has cond(Sigma)-size entries: the differences lose ~|alpha| eps / h absolutely
+    tol = 1e-5 * np.abs(grad).max() + 10 * np.finfo(float).eps * np.abs(g["alpha"]).sum() * float(g["theta"][2]) ** 2 / h
+    assert np.abs(fd - grad).max() <= tol
+
+
 @pytest.mark.parametrize("name", SMALL)
 def test_line_covariance_and_ei(golden, name):
     g = golden(name)
