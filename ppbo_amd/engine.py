@@ -120,10 +120,10 @@ class Engine:
         return tot.value, cnt.value
 
     # ---- K1 / K2 --------------------------------------------------------
-    def gram(self, X, theta, kernel="SE_kernel", shrink=SHRINKAGE):
+    def gram(self, X, theta, kernel="SE_kernel", shrink=SHRINKAGE, out=None):
         X = self.dev(X)
         N, D = X.shape
-        S = self.empty(N, N)
+        S = self.empty(N, N) if out is None else out
         rc = self.lib.ppbo_gram(self.ctx, KERNEL_IDS[kernel], _ptr(X), N, D, self._theta(theta), shrink, _ptr(S),
                                 self._stream())
         self._check(rc, "ppbo_gram")
