@@ -52,7 +52,7 @@ def test_dgemm_mfma_layout_is_not_transposed(eng):
     assert np.array_equal(out, B)
 
 
-@pytest.mark.parametrize("N", [64, 100, 200, 512, 650, 1031])
+@pytest.mark.parametrize("N", [1, 17, 63, 64, 65, 100, 129, 200, 512, 650, 1031, 2500])
 def test_potrf_and_inverse(eng, N):
     rng = np.random.default_rng(N)
     Q = rng.standard_normal((N, N))
@@ -64,14 +64,31 @@ def test_potrf_and_inverse(eng, N):
     assert np.abs(Ai - Ai.T).max() <= 1e-12 * np.abs(Ai).max()
 
 
-def test_potrf_reports_not_pd(eng):
+@pytest.mark.parametrize("bad", [0, 63, 64, 150, 199])
+def test_potrf_reports_not_pd(eng, bad):
+    """LAPACK's info: the 1-based order of the first leading minor that is not positive definite."""
     from ppbo_amd.engine import NotPositiveDefinite
     N = 200
-    A = np.eye(N)
-    A[150, 150] = -1.0
+    A = np.eye(N) + 0.01
+    A[bad, bad] = -1.0
     with pytest.raises(NotPositiveDefinite) as ei:
         eng.potrf_(eng.dev(A))
-    assert ei.value.info == 151
+    assert ei.value.info == bad + 1
+
+
+@pytest.mark.parametrize("N,pad", [(200, 8), (257, 3)])
+def test_potrf_with_leading_dimension(eng, N, pad):
+    """lda > N (and odd): the factor lands in the view, the padding columns are untouched."""
+    rng = np.random.default_rng(N + pad)
+    Q = rng.standard_normal((N, N))
+    A = Q @ Q.T + N * np.eye(N)
+    buf = eng.dev(np.full((N, N + pad), 7.0))
+    view = buf[:, :N]
+    view.copy_(eng.dev(A))
+    eng.potrf_(view)
+    out = host(buf)
+    assert rel(np.tril(out[:, :N]), np.linalg.cholesky(A)) < 1e-12
+    assert np.all(out[:, N:] == 7.0)
 
 
 # ---------------------------------------------------------------- K1 / K2
