@@ -190,9 +190,9 @@ __global__ __launch_bounds__(256) void trsm_mfma_kernel(double* __restrict__ A, 
 // recursion so that the longest dependent FMA chain is 28 + 8 + 8 instead of 120 (the last block's inverse
 // sits on the panel's critical path).  Lanes 0-7 / 8-15: column (lane & 7) of the inverse of the leading /
 // trailing 8x8 triangle; then lanes 0-7: their column of X21 = -inv(L22) (L21 inv(L11)).
-// Rinv holds the reciprocal pivots left by the factorization.
+// Rinv holds the reciprocal pivots left by the factorization.  // out points at the (0,0) element of the 16x16 result, ldo is its row pitch.
 __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, const double* __restrict__ Rinv,
-                                              double* __restrict__ Li, int b, int lane) {
+                                              double* __restrict__ out, int ldo, int b, int lane) {
   if (lane >= 16) return;
   const int h = lane >> 3, cc = lane & 7, c0 = 16 * b, o = c0 + 8 * h;
   double y[8];
@@ -205,8 +205,8 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
   }
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    Li[(b * 16 + 8 * h + r) * 18 + 8 * h + cc] = y[r];
-    if (h == 1) Li[(b * 16 + r) * 18 + 8 + cc] = 0.0;      // the block above the diagonal
+    out[(8 * h + r) * ldo + 8 * h + cc] = y[r];
+    if (h == 1) out[r * ldo + 8 + cc] = 0.0;               // the block above the diagonal
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -224,8 +224,8 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
     for (int r = 0; r < 8; ++r) {
       double v = 0.0;
 #pragma unroll
-      for (int j = 0; j <= r; ++j) v -= Li[(b * 16 + 8 + r) * 18 + 8 + j] * tv[j];
-      Li[(b * 16 + 8 + r) * 18 + cc] = v;
+      for (int j = 0; j <= r; ++j) v -= out[(8 + r) * ldo + 8 + j] * tv[j];
+      out[(8 + r) * ldo + cc] = v;
     }
   }
 }
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
             rowv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xs[(16 * c + lr) * BLD + 4 * kk + lk], rowv[c], 0, 0, 0);
         }
       }
-      if (s >= 1 && wave == 3) invert_diag16(Ab, Rinv, Li, s - 1, lane);
+      if (s >= 1 && wave == 3) invert_diag16(Ab, Rinv, Li + (s - 1) * 16 * 18, 18, s - 1, lane);
       if (s >= 2 && row0 < N) solve_block(s - 2);
     }
     __syncthreads();
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
     if (s < 3) __syncthreads();
   }
   if (!s_fail) {
-    if (wave == 0) invert_diag16(Ab, Rinv, Li, 3, lane);
+    if (wave == 0) invert_diag16(Ab, Rinv, Li + 3 * 16 * 18, 18, 3, lane);
     else if (row0 < N) solve_block(2);
   }
   __syncthreads();
@@ -546,28 +546,78 @@ __global__ __launch_bounds__(256) void scatter_diag_kernel(double* __restrict__ 
   }
 }
 
-// inverse of the 64x64 diagonal blocks of lower-triangular L; lane = column of the inverse.
-// The running column lives in LDS ([r][lane], conflict free); L entries are broadcast reads.
-__global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict__ L, int ldl, int N,
-                                                        double* __restrict__ Li, int ldi) {
-  __shared__ __attribute__((aligned(16))) double Ls[NB * NB];
-  __shared__ double Ys[NB * NB];
+// inverse of the 64x64 diagonal blocks of lower-triangular L, one 256-thread workgroup per block:
+// the four 16x16 diagonal triangles are inverted by one wavefront each (invert_diag16), then two
+// doubling levels X21 = -inv(L22) (L21 inv(L11)) on the matrix cores, operands in LDS.
+// (The first version -- one wavefront, lane = column, 64 sequential rows -- took 64 us per launch.)
+__global__ __launch_bounds__(256) void trtri_diag_kernel(const double* __restrict__ L, int ldl, int N,
+                                                         double* __restrict__ Li, int ldi) {
+  __shared__ __attribute__((aligned(16))) double Ls[NB * BLD];   // the block of L
+  __shared__ __attribute__((aligned(16))) double Is[NB * BLD];   // its inverse
+  __shared__ __attribute__((aligned(16))) double Ts[32 * BLD];   // L21 inv(L11) of the current level
+  __shared__ double Rinv[NB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
   const int b0 = blockIdx.x * NB;
   const int kb = (N - b0 < NB) ? (N - b0) : NB;
-  for (int e = threadIdx.x; e < NB * NB; e += 64) {
-    const int r = e / NB, c = e - r * NB;
-    Ls[e] = (r < kb && c <= r) ? L[(size_t)(b0 + r) * ldl + b0 + c] : ((r == c) ? 1.0 : 0.0);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int e = t + 256 * q, r = e >> 6, c = e & 63;
+    const double v = (r < kb && c <= r) ? L[(size_t)(b0 + r) * ldl + b0 + c] : 0.0;
+    Ls[r * BLD + c] = (r >= kb && r == c) ? 1.0 : v;            // identity padding of a partial last block
+    Is[r * BLD + c] = 0.0;
+    if (r == c) Rinv[r] = (r < kb) ? 1.0 / v : 1.0;
   }
   __syncthreads();
-  const int c = threadIdx.x;
-  for (int r = 0; r < NB; ++r) {
-    double v = (r == c) ? 1.0 : 0.0;
-    const double* lr = Ls + r * NB;
-#pragma unroll 8
-    for (int k = 0; k < r; ++k) v -= lr[k] * Ys[k * NB + c];
-    v = (r >= c) ? v / lr[r] : 0.0;
-    Ys[r * NB + c] = v;
-    if (c < kb && r < kb) Li[(size_t)(b0 + r) * ldi + b0 + c] = v;
+  invert_diag16(Ls, Rinv, Is + (16 * wave) * BLD + 16 * wave, BLD, wave, lane);
+  __syncthreads();
+  // 16 -> 32: waves 0 and 1 own the two 32x32 diagonal blocks
+  if (wave < 2) {
+    const int o = 32 * wave;
+    double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)       // T = L21 inv(L11)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[(o + 16 + lr) * BLD + o + 4 * kk + lk],
+                                                 Is[(o + 4 * kk + lk) * BLD + o + lr], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ts[(16 * wave + lk + 4 * r) * BLD + lr] = acc[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)       // X21 = -inv(L22) T
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Is[(o + 16 + lr) * BLD + o + 16 + 4 * kk + lk],
+                                               Ts[(16 * wave + 4 * kk + lk) * BLD + lr], x, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Is[(o + 16 + lk + 4 * r) * BLD + o + lr] = x[r];
+  }
+  __syncthreads();
+  // 32 -> 64: one 16x16 tile of the 32x32 products per wave
+  {
+    const int tr = wave >> 1, tc = wave & 1;
+    double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)       // T = L21 inv(L11), L21 = L[32:64, 0:32]
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[(32 + 16 * tr + lr) * BLD + 4 * kk + lk],
+                                                 Is[(4 * kk + lk) * BLD + 16 * tc + lr], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ts[(16 * tr + lk + 4 * r) * BLD + 16 * tc + lr] = acc[r];
+    __syncthreads();
+    double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)       // X21 = -inv(L22) T, inv(L22) = Is[32:64, 32:64]
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Is[(32 + 16 * tr + lr) * BLD + 32 + 4 * kk + lk],
+                                               Ts[(4 * kk + lk) * BLD + 16 * tc + lr], x, 0, 0, 0);
+    __syncthreads();                     // every wave has read inv(L11) / inv(L22) before the corner is written
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Is[(32 + 16 * tr + lk + 4 * r) * BLD + 16 * tc + lr] = x[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int e = t + 256 * q, r = e >> 6, c = e & 63;
+    if (r < kb && c < kb) Li[(size_t)(b0 + r) * ldi + b0 + c] = Is[r * BLD + c];
   }
 }
 
@@ -696,7 +746,7 @@ int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hi
 int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d_Linv, int ldi, hipStream_t s) {
   PPBO_HIP_CHECK(ctx, hipMemsetAsync(d_Linv, 0, (size_t)N * ldi * sizeof(double), s));
   const int nblk = (N + NB - 1) / NB;
-  trtri_diag_kernel<<<nblk, 64, 0, s>>>(d_L, ldl, N, d_Linv, ldi);
+  trtri_diag_kernel<<<nblk, 256, 0, s>>>(d_L, ldl, N, d_Linv, ldi);
   PPBO_LAUNCH_CHECK(ctx);
   if (N <= NB) return 0;
   double* Tw = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG2, (size_t)N * N / 2 * sizeof(double) + 4096);
