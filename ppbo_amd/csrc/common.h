@@ -90,6 +90,19 @@ static inline KernParams make_kern_params(int kernel_id, const double theta[3]) 
 #ifdef __HIPCC__
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// Write-through ("sc1") global stores for bulk results that the NEXT kernel reads: a plain store leaves the
+// line dirty in the XCD's L2 and the whole dirty footprint is written back when the kernel ends -- serial
+// time on a chain of dependent launches (measured: 3-4 us per Cholesky step with 16 MB of dirty tiles).
+// hipcc does not count an asm store in vmcnt; that only makes its waits for earlier loads conservative.
+__device__ __forceinline__ void store_through(double* p, double v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+typedef double double2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_through2(double* p, double x, double y) {
+  const double2_t v = {x, y};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 // 64-lane wavefront reductions (gfx950: wave = 64)
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

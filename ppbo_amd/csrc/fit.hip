@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void form_shifted_kernel(const double* __restr
     sq += h * h;
     if (j == i) { dg = h; h += lam; }
     else rs += fabs(h);
-    dst[j] = h;
+    store_through(dst + j, h);
   }
   if (rowstats) {
     rs = wave_sum(rs);

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(GC::NT, (GC::NT == 512) ? 4 : 2) void dgemm_kernel(
         double* c = g.C + (size_t)row * g.ldc + col;
         double v = g.alpha * acc[i][j][r];
         if (!preload && g.beta != 0.0) v += g.beta * (*c);
-        *c = v;
+        store_through(c, v);
       }
     }
 }

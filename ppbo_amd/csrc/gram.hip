@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ X,
     const int gj = j0 + tx * 4;
     double* dst = Sigma + (size_t)gi * N + gj;
     if (vec_ok && gj + 3 < N) {
-      *reinterpret_cast<double2*>(dst) = make_double2(v[a][0], v[a][1]);
-      *reinterpret_cast<double2*>(dst + 2) = make_double2(v[a][2], v[a][3]);
+      store_through2(dst, v[a][0], v[a][1]);
+      store_through2(dst + 2, v[a][2], v[a][3]);
     } else {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ X,
     const double* src = Tt + r * TP + tx * 4;
     double* dst = Sigma + (size_t)gi * N + gj;
     if (vec_ok && gj + 3 < N) {
-      *reinterpret_cast<double2*>(dst) = make_double2(src[0], src[1]);
-      *reinterpret_cast<double2*>(dst + 2) = make_double2(src[2], src[3]);
+      store_through2(dst, src[0], src[1]);
+      store_through2(dst + 2, src[2], src[3]);
     } else {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
     }
     if (full) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ddst[(size_t)(4 * r) * N + j * 16] = v[r];
+      for (int r = 0; r < 4; ++r) store_through(ddst + (size_t)(4 * r) * N + j * 16, v[r]);
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
       const double2 m = *reinterpret_cast<const double2*>(Ts + c * LT + mp);
       double* dst = mdst + (size_t)(j * 16 + 8 * h) * N;
       const int gi = j0 + j * 16 + c, gj = i0 + w * 16 + mp;
-      if (full && vec_ok) *reinterpret_cast<double2*>(dst) = m;
+      if (full && vec_ok) store_through2(dst, m.x, m.y);
       else if (gi < N) {
         if (gj < N) dst[0] = m.x;
         if (gj + 1 < N) dst[1] = m.y;

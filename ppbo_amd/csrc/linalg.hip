@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int gr = i0 + 16 * wave + lk + 4 * r, gc = j0 + 16 * jt + lr;
-            if (gr < N && gc < N) A[(size_t)gr * lda + gc] = acc[jt][r];
+            if (gr < N && gc < N) store_through(A + (size_t)gr * lda + gc, acc[jt][r]);
           }
       }
       __syncthreads();

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
       const double k0 = kern_finish<KID>(s0, p), k1 = kern_finish<KID>(s1, p);
       if (Kt) {
         double* dst = Kt + (size_t)(row0 + r) * ldk + c0;
-        if (vec) *reinterpret_cast<double2*>(dst) = make_double2(k0, k1);
+        if (vec) store_through2(dst, k0, k1);      // 1 GB streamed out once, read back by the next kernel
         else {
           if (c0 < M) dst[0] = k0;
           if (c0 + 1 < M) dst[1] = k1;

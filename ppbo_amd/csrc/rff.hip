@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void rff_project_kernel(const double* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + j * 16 + lr;
-      if (n < N) Phi[(size_t)f * N + n] = scale * rff_cos(acc[j][r]);
+      if (n < N) store_through(Phi + (size_t)f * N + n, scale * rff_cos(acc[j][r]));
     }
   }
 }

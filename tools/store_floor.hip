@@ -17,7 +17,13 @@ __global__ __launch_bounds__(256) void fill_linear(double2* __restrict__ p, size
 }
 
 // tile fill: block -> TR x TC tile of an N x N row-major matrix, 32 lanes = one 512 B row segment
-template <int TR, int TC>
+typedef double double2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_through2(double* p, double x, double y) {   // write-through: line leaves the L2 at once
+  const double2_t v = {x, y};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int TR, int TC, int WT = 0>
 __global__ __launch_bounds__(256) void fill_tile(double* __restrict__ S, int N, double v) {
   const int ntc = N / TC;
   const int bi = blockIdx.x / ntc, bj = blockIdx.x % ntc;
@@ -27,7 +33,9 @@ __global__ __launch_bounds__(256) void fill_tile(double* __restrict__ S, int N, 
 #pragma unroll
   for (int a = 0; a < TR / RPP; ++a) {
     const int r = a * RPP + r0;
-    *reinterpret_cast<double2*>(S + (size_t)(bi * TR + r) * N + bj * TC + c2) = make_double2(v, v + r);
+    double* dst = S + (size_t)(bi * TR + r) * N + bj * TC + c2;
+    if (WT) store_through2(dst, v, v + r);
+    else *reinterpret_cast<double2*>(dst) = make_double2(v, v + r);
   }
 }
 
@@ -103,6 +111,8 @@ int main() {
     timeit(tag, bytes, [&] { fill_linear<1><<<1024, 256>>>((double2*)d, n / 2, 1.0); });
     snprintf(tag, sizeof tag, "N=%d tile 64x64", N);
     timeit(tag, bytes, [&] { fill_tile<64, 64><<<(N / 64) * (N / 64), 256>>>(d, N, 1.0); });
+    snprintf(tag, sizeof tag, "N=%d tile 64x64 write-through", N);
+    timeit(tag, bytes, [&] { fill_tile<64, 64, 1><<<(N / 64) * (N / 64), 256>>>(d, N, 1.0); });
     snprintf(tag, sizeof tag, "N=%d tile 32x64", N);
     timeit(tag, bytes, [&] { fill_tile<32, 64><<<(N / 32) * (N / 64), 256>>>(d, N, 1.0); });
     snprintf(tag, sizeof tag, "N=%d tile 32x128", N);
