@@ -10,6 +10,9 @@ using namespace gemm64;
 using GCBig = Cfg<4, 2, 2, 4>;     // 128 x 128 tile, 8 wavefronts of 32 x 64 (4 waves/SIMD): large products
 using GCSmall = Cfg<2, 2, 2, 2>;   // 64 x 64 tile, 4 wavefronts of 32 x 32: short-K panel updates, where the
                                    // grid must put >= 2 wavefronts on every SIMD to reach the 64-cycle MFMA rate
+using GCTiny = Cfg<2, 2, 1, 1>;    // 32 x 32 tile, 4 wavefronts of 16 x 16: products with so few 64 x 64 tiles that a CU
+                                   // would hold ONE workgroup, whose single stage of prefetch (one k-chunk = 1024 MFMA
+                                   // cycles) cannot cover a memory round trip; four small workgroups per CU can
 
 template <class GC, int ALAY, int BLAY>
 __global__ __launch_bounds__(GC::NT, (GC::NT == 512) ? 4 : 2) void dgemm_kernel(GemmArgs g) {
@@ -102,6 +105,9 @@ int ppbo_gemm_launch(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, h
   const long long big_tiles = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.batch > 1 ? g.batch : 1) /
                               (g.lower_only ? 2 : 1);
   if (big_tiles >= 1024 && g.K >= 256) return launch_cfg<GCBig>(ctx, g, transA, transB, s);
+  const long long small_tiles = (long long)((g.M + 63) / 64) * ((g.N + 63) / 64) * (g.batch > 1 ? g.batch : 1) /
+                                (g.lower_only ? 2 : 1);
+  if (small_tiles <= 384 && g.K >= 128) return launch_cfg<GCTiny>(ctx, g, transA, transB, s);
   return launch_cfg<GCSmall>(ctx, g, transA, transB, s);
 }
 
