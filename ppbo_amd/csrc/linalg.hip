@@ -648,29 +648,52 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
   if (lane == 0) y[i] = s;
 }
 
-// partial[split][j] = sum_{i in split, i >= (lower ? j : 0)} T[i][j] x[i]
+// y = T^T x in two deterministic passes.  partial[split][j] = sum_{i in split, i >= (lower ? j : 0)} T[i][j] x[i]
+// with GT_ROWS rows per split: every lane keeps all its loads in flight (the first version looped over 64
+// rows and was latency-bound at 0.8 TB/s); splits that lie entirely above the diagonal are skipped by both
+// passes.
+constexpr int GT_ROWS = 16;
+
 __global__ __launch_bounds__(256) void gemvT_partial_kernel(const double* __restrict__ T, int N, int ldt,
                                                             const double* __restrict__ x,
-                                                            double* __restrict__ partial, int rows_per_split,
-                                                            int lower) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+                                                            double* __restrict__ partial, int lower) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int i0 = blockIdx.y * GT_ROWS;
+  if (lower && i0 + GT_ROWS <= (int)blockIdx.x * 256) return;      // no row of this split reaches these columns
   if (j >= N) return;
-  int i0 = blockIdx.y * rows_per_split;
-  int i1 = i0 + rows_per_split;
-  if (i1 > N) i1 = N;
-  if (lower && i0 < j) i0 = j;
+  double v[GT_ROWS];
+#pragma unroll
+  for (int r = 0; r < GT_ROWS; ++r) {
+    const int i = i0 + r;
+    v[r] = (i < N && (!lower || i >= j)) ? T[(size_t)i * ldt + j] : 0.0;
+  }
   double s = 0.0;
-  for (int i = i0; i < i1; ++i) s += T[(size_t)i * ldt + j] * x[i];
+#pragma unroll
+  for (int r = 0; r < GT_ROWS; ++r) s += v[r] * ((i0 + r < N) ? x[i0 + r] : 0.0);
   partial[(size_t)blockIdx.y * N + j] = s;
 }
 
+// y[j] = sum over the splits that were written; 16 columns x 16 split groups per workgroup, fixed summation order
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const double* __restrict__ partial, int n_split, int N,
-                                                        double* __restrict__ y) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= N) return;
+                                                        double* __restrict__ y, int lower) {
+  __shared__ double sh[16][17];
+  const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + c;
+  // first split whose partial kernel ran for this column's 256-column block
+  const int first = lower ? ((j / 256) * 256) / GT_ROWS : 0;
   double s = 0.0;
-  for (int k = 0; k < n_split; ++k) s += partial[(size_t)k * N + j];
-  y[j] = s;
+  if (j < N) {
+#pragma unroll 4
+    for (int k = first + grp; k < n_split; k += 16) s += partial[(size_t)k * N + j];
+  }
+  sh[grp][c] = s;
+  __syncthreads();
+  if (grp == 0 && j < N) {
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += sh[g][c];
+    y[j] = t;
+  }
 }
 
 __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x, const double* __restrict__ y,
@@ -797,12 +820,11 @@ int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const doub
   if (!trans) {
     gemv_rows_kernel<<<(N + 3) / 4, 256, 0, s>>>(d_T, N, ldt, d_x, d_y, lower);
   } else {
-    const int n_split = 32;
-    const int rows = (N + n_split - 1) / n_split;
+    const int n_split = (N + GT_ROWS - 1) / GT_ROWS;
     double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, (size_t)n_split * N * sizeof(double));
     if (!part) return (int)hipErrorOutOfMemory;
-    gemvT_partial_kernel<<<dim3((N + 255) / 256, n_split), 256, 0, s>>>(d_T, N, ldt, d_x, part, rows, lower);
-    sum_slabs_kernel<<<(N + 255) / 256, 256, 0, s>>>(part, n_split, N, d_y);
+    gemvT_partial_kernel<<<dim3((N + 255) / 256, n_split), 256, 0, s>>>(d_T, N, ldt, d_x, part, lower);
+    sum_slabs_kernel<<<(N + 15) / 16, 256, 0, s>>>(part, n_split, N, d_y, lower);
   }
   PPBO_LAUNCH_CHECK(ctx);
   return 0;

@@ -64,6 +64,21 @@ def test_potrf_and_inverse(eng, N):
     assert np.abs(Ai - Ai.T).max() <= 1e-12 * np.abs(Ai).max()
 
 
+@pytest.mark.parametrize("N", [1, 15, 257, 1000, 2048])
+@pytest.mark.parametrize("trans", [False, True])
+@pytest.mark.parametrize("lower", [False, True])
+def test_dgemv(eng, N, trans, lower):
+    rng = np.random.default_rng(N + 2 * trans + lower)
+    A = rng.standard_normal((N, N))
+    x = rng.standard_normal(N)
+    y = host(eng.dgemv(A, x, trans=trans, lower=lower))
+    Ae = np.tril(A) if lower else A
+    ref = (Ae.T if trans else Ae) @ x
+    assert np.abs(y - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()) * np.sqrt(N)
+    y2 = host(eng.dgemv(A, x, trans=trans, lower=lower))
+    assert np.array_equal(y, y2)            # fixed summation order: bitwise reproducible
+
+
 @pytest.mark.parametrize("bad", [0, 63, 64, 150, 199])
 def test_potrf_reports_not_pd(eng, bad):
     """LAPACK's info: the 1-based order of the first leading minor that is not positive definite."""
