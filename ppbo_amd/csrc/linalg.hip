@@ -233,13 +233,13 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
 // ---- ONE launch per panel step, with one step of lookahead.
 // Launch k holds two independent kinds of workgroup:
 //   panel part (the first nP workgroups, one per 48 rows below the panel): first applies panel k-1's
-//     rank-64 update to block column k only (its own 64 rows and, redundantly, the diagonal block), then
+//     rank-64 update to block column k only (its own 48 rows and, redundantly, the diagonal block), then
 //     factors the diagonal block ITSELF -- the factor never travels between workgroups, the redundant
 //     flops are free on <= 42 of 256 CUs -- and solves its 48 rows against it.  Nobody may overwrite A_kk
 //     while another workgroup can still be reading it, so workgroup 0 parks L_kk in a side buffer
 //     (diag_out, one 64x64 slot per panel) that scatter_diag_kernel copies back once at the end;
-//   update part (the remaining workgroups, one per 64x64 tile): panel k-1's trailing update on block
-//     columns >= k+1, i.e. everything the panel part does not touch.
+//   update part (the remaining workgroups, persistent over the 64x64 tiles): panel k-1's trailing update
+//     on block columns >= k+1, i.e. everything the panel part does not touch.
 // Block column k therefore meets panel k-1's update one launch late, inside the panel part, and the
 // bulk trailing update runs in the shadow of the latency-bound panel instead of after it: a step costs
 // max(panel, update) and one launch instead of panel + update and two.  No workgroup reads what another
