@@ -146,7 +146,7 @@ __device__ __forceinline__ double gram_finish(double r2, const KernParams& p, do
 // mirror image as 16-byte pieces (8 lanes = one line).  Stores therefore start after the first
 // quarter of the wave's arithmetic and overlap the rest.  HBM-write bound: 8 N^2 + 8 N D bytes.
 template <int KID, int DP>
-__global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict__ X, int N, int D, KernParams p,
+__global__ __launch_bounds__(512) void gram_mfma_kernel(const double* __restrict__ X, int N, int D, KernParams p,
                                                          double shrink, double* __restrict__ Sigma, int nt) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int LD = DP + 2;       // 2*odd: fragment reads and panel writes are bank-conflict free
@@ -155,41 +155,52 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
   double* Xb = Xa + TS * LD;       // [64][LD]  (-2 x_j)
   double* na = Xb + TS * LD;       // [64] |x_i|^2
   double* nb = na + TS;            // [64] |x_j|^2
-  double* Tw = nb + TS;            // [4 waves][16][LT]
+  double* Tw = nb + TS;            // [8 waves][16][LT]
 
-  const int t = blockIdx.x;
-  const double q = 2.0 * nt + 1.0;
-  int bi = (int)floor((q - sqrt(q * q - 8.0 * (double)t)) * 0.5);
-  while (bi > 0 && t < bi * nt - bi * (bi - 1) / 2) --bi;
-  while (t >= (bi + 1) * nt - (bi + 1) * bi / 2) ++bi;
-  const int bj = bi + (t - (bi * nt - bi * (bi - 1) / 2));
+  // off-diagonal tiles first (row by row over the strict upper triangle), the nt diagonal tiles last: the
+  // diagonal tiles have no mirror image to write, and the last-dispatched workgroups are the ones that land as
+  // a third tile on an already busy CU (528 tiles on 256 CUs at N = 2048)
+  const int n1 = nt - 1, n_off = n1 * (n1 + 1) / 2;
+  int bi, bj;
+  if ((int)blockIdx.x >= n_off) {
+    bi = bj = blockIdx.x - n_off;
+  } else {
+    const int t = blockIdx.x;
+    const double q = 2.0 * n1 + 1.0;
+    bi = (int)floor((q - sqrt(q * q - 8.0 * (double)t)) * 0.5);
+    while (bi > 0 && t < bi * n1 - bi * (bi - 1) / 2) --bi;
+    while (t >= (bi + 1) * n1 - (bi + 1) * bi / 2) ++bi;
+    bj = bi + (t - (bi * n1 - bi * (bi - 1) / 2)) + 1;
+  }
   const int i0 = bi * TS, j0 = bj * TS;
 
-  // 4 lanes per row: each loads DP/4 elements of both panels, norms by two xor-shuffles
+  // 4 lanes per row, DP/4 elements each; threads 0-255 stage the row panel, 256-511 the column panel
+  // (scaled by -2); squared norms by two xor-shuffles
   {
     constexpr int Q = DP / 4;
-    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
-    double xa[Q], xb[Q];
-    double sa = 0.0, sb = 0.0;
+    const int half = threadIdx.x >> 8, r = (threadIdx.x & 255) >> 2, part = threadIdx.x & 3;
+    const int g0 = half ? j0 : i0;
+    double* Xp = half ? Xb : Xa;
+    const double sc = half ? -2.0 : 1.0;
+    double xv[Q];
+    double sn = 0.0;
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
       const int d = part * Q + k;
-      xa[k] = (d < D && i0 + r < N) ? X[(size_t)(i0 + r) * D + d] : 0.0;
-      xb[k] = (d < D && j0 + r < N) ? X[(size_t)(j0 + r) * D + d] : 0.0;
+      xv[k] = (d < D && g0 + r < N) ? X[(size_t)(g0 + r) * D + d] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
-      sa += xa[k] * xa[k];
-      sb += xb[k] * xb[k];
-      Xa[r * LD + part * Q + k] = xa[k];
-      Xb[r * LD + part * Q + k] = -2.0 * xb[k];
+      sn += xv[k] * xv[k];
+      Xp[r * LD + part * Q + k] = sc * xv[k];
     }
-    sa += __shfl_xor(sa, 1, 64); sa += __shfl_xor(sa, 2, 64);
-    sb += __shfl_xor(sb, 1, 64); sb += __shfl_xor(sb, 2, 64);
-    if (part == 0) { na[r] = sa; nb[r] = sb; }
+    sn += __shfl_xor(sn, 1, 64); sn += __shfl_xor(sn, 2, 64);
+    if (part == 0) (half ? nb : na)[r] = sn;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // wave = (row strip w of 16 rows, column half jh of 32 columns): eight wavefronts keep four per SIMD in
+  // flight at two tiles per CU, and a wave's first stores leave after half as much arithmetic
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, w = wv & 3, jh = wv >> 2;
   const int lr = lane & 15, lk = lane >> 4;
   double af[DP / 4], nai[4];
 #pragma unroll
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
   const double diagv = one_minus * p.sf2 + shrink * p.sf2;
   const bool vec_ok = ((N & 1) == 0);
   const bool full = (i0 + TS <= N) && (j0 + TS <= N);
-  double* Ts = Tw + w * 16 * LT;
+  double* Ts = Tw + wv * 16 * LT;
   // direct piece: rows lk+4r of the wave's strip, column lr of sub-tile j
   double* ddst = Sigma + (size_t)(i0 + w * 16 + lk) * N + j0 + lr;
   // mirror piece: lane = (row c = lane>>3 (+8), column pair 2*(lane&7)) of the transposed sub-tile
@@ -210,7 +221,8 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict
   double* mdst = Sigma + (size_t)(j0 + mc) * N + i0 + w * 16 + mp;
 
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = 2 * jh + jj;
     double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < DP / 4; ++kk)
@@ -317,16 +329,16 @@ int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, con
 #define GM_LAUNCH(DPV)                                                                                       \
   do {                                                                                                       \
     constexpr int LDv = DPV + 2;                                                                             \
-    constexpr int body = 2 * TS * LDv + 2 * TS + 4 * 16 * 18;                                                \
+    constexpr int body = 2 * TS * LDv + 2 * TS + 8 * 16 * 18;                                                \
     const size_t lds = (size_t)body * sizeof(double);                                                        \
     if (kernel_id == PPBO_KERNEL_SE) {                                                                       \
       if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gram_mfma_kernel<PPBO_KERNEL_SE, DPV>,     \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-      gram_mfma_kernel<PPBO_KERNEL_SE, DPV><<<nblk, 256, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);       \
+      gram_mfma_kernel<PPBO_KERNEL_SE, DPV><<<nblk, 512, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);       \
     } else {                                                                                                 \
       if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gram_mfma_kernel<PPBO_KERNEL_RQ, DPV>,     \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-      gram_mfma_kernel<PPBO_KERNEL_RQ, DPV><<<nblk, 256, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);       \
+      gram_mfma_kernel<PPBO_KERNEL_RQ, DPV><<<nblk, 512, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);       \
     }                                                                                                        \
   } while (0)
     if (D <= 4) GM_LAUNCH(4);
