@@ -25,79 +25,82 @@ constexpr double INV_SQRT_4PI = 0.28209479177387814347;
   }
 }
 
-// cos(x) for |x| < 1.6e6 by a three-constant Cody-Waite reduction to [-pi/4, pi/4] and the fdlibm
-// minimax kernels (about 35 fp64 instructions, <= 1 ulp); larger arguments take the library path.
-// The RFF phases w.x + b are O(sqrt(D)/l) (tens), far inside the fast range.
+// cos(x) for |x| < 1.6e6 as -(-1)^k sin(r), |x| = (2k+1) pi/2 + r with |r| <= pi/2: Cody-Waite reduction by
+// four 33-bit pieces of pi/2 (the odd multiplier is exact), then ONE odd minimax polynomial of degree 19
+// (fit error 3e-22, tools/expfit.py has the recipe) -- about 24 fp64 instructions and <= 1 ulp, against ~40 for
+// the usual reduction to pi/4 that evaluates a sine AND a cosine kernel and selects.  Larger arguments take
+// the library path.  The RFF phases w.x + b are O(sqrt(D)/l) (tens), far inside the fast range.
 __device__ __forceinline__ double rff_cos(double x) {
   const double ax = fabs(x);
   if (!(ax < 1.6e6)) return cos(x);
-  const double kf = rint(ax * 6.36619772367581382433e-01);
-  double r = fma(-kf, 1.57079632673412561417e+00, ax);
-  r = fma(-kf, 6.07710050630396597660e-11, r);
-  r = fma(-kf, 2.02226624871116645580e-21, r);
-  r = fma(-kf, 8.47842766036889956997e-32, r);
+  const double kf = rint(fma(ax, 3.18309886183790671538e-01, -0.5));
+  const double n = fma(2.0, kf, 1.0);
+  double r = fma(-n, 1.57079632673412561417e+00, ax);
+  r = fma(-n, 6.07710050630396597660e-11, r);
+  r = fma(-n, 2.02226624871116645580e-21, r);
+  r = fma(-n, 8.47842766036889956997e-32, r);
   const double z = r * r;
-  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
-                    2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03),
-                    -1.66666666666666324348e-01);
-  const double sn = fma(z * r, ps, r);
-  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
-                    -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03),
-                    4.16666666666666019037e-02);
-  const double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
-  const int q = ((int)kf) & 3;            // cos(r + q pi/2)
-  const double v = (q & 1) ? sn : cs;
-  return (q == 1 || q == 2) ? -v : v;
+  double q = -0x1.26805104f0fb2p-57;
+  q = fma(q, z, 0x1.94fe99353aaa5p-49);
+  q = fma(q, z, -0x1.ae7eb995a1519p-41);
+  q = fma(q, z, 0x1.61246051b86e7p-33);
+  q = fma(q, z, -0x1.ae64567d5b22ap-26);
+  q = fma(q, z, 0x1.71de3a5569d7bp-19);
+  q = fma(q, z, -0x1.a01a01a019fdbp-13);
+  q = fma(q, z, 0x1.1111111111111p-7);
+  q = fma(q, z, -0x1.5555555555555p-3);
+  const double sn = fma(r * z, q, r);
+  return (((int)kf) & 1) ? sn : -sn;
 }
 
-// Phi tile [64 features x 64 points] with the phase w_f.x_n + b_f on the fp64 matrix cores:
-//   a_f = ( w_f , b_f , 0.. )   b_n = ( x_n , 1 , 0.. )   (depth DP + 4, compile time)
-// wave w owns feature rows 16w..16w+15; every store instruction writes four full 128-byte lines.
+// Phi tile [64 features x 64 points] with the phase w_f.x_n on the fp64 matrix cores (depth DP, compile
+// time) and b_f added in the epilogue.  Eight wavefronts per tile: wave = (16 feature rows, 32 points), so a
+// CU holding two tiles keeps four wavefronts per SIMD busy and the first (write-through) stores leave after
+// half a strip's arithmetic; every store instruction writes four full 128-byte lines.
 template <int DP>
-__global__ __launch_bounds__(256) void rff_project_kernel(const double* __restrict__ X, int N, int D,
+__global__ __launch_bounds__(512) void rff_project_kernel(const double* __restrict__ X, int N, int D,
                                                           const double* __restrict__ W, int F,
                                                           const double* __restrict__ b, double scale,
                                                           double* __restrict__ Phi) {
-  constexpr int KA = DP + 4, LD = KA + 2, Q = DP / 4;
+  constexpr int LD = DP + 2, Q = DP / 4;
   __shared__ __attribute__((aligned(16))) double Wa[TS * LD];
   __shared__ __attribute__((aligned(16))) double Xb[TS * LD];
   const int f0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
   {
-    const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+    // threads 0-255 stage the feature panel, 256-511 the point panel; 4 lanes per row
+    const int half = threadIdx.x >> 8, r = (threadIdx.x & 255) >> 2, part = threadIdx.x & 3;
+    const double* src = half ? X : W;
+    double* dst = half ? Xb : Wa;
+    const int g = (half ? n0 : f0) + r, lim = half ? N : F;
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
       const int d = part * Q + k;
-      Wa[r * LD + d] = (d < D && f0 + r < F) ? W[(size_t)(f0 + r) * D + d] : 0.0;
-      Xb[r * LD + d] = (d < D && n0 + r < N) ? X[(size_t)(n0 + r) * D + d] : 0.0;
+      dst[r * LD + d] = (d < D && g < lim) ? src[(size_t)g * D + d] : 0.0;
     }
-    Wa[r * LD + DP + part] = (part == 0 && f0 + r < F) ? b[f0 + r] : 0.0;
-    Xb[r * LD + DP + part] = (part == 0) ? 1.0 : 0.0;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, w = wv & 3, jh = wv >> 2;
   const int lr = lane & 15, lk = lane >> 4;
-  double4_t acc[4];
+  double af[Q], bv[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = double4_t{0.0, 0.0, 0.0, 0.0};
-  double af[KA / 4], bf[4][KA / 4];
-#pragma unroll
-  for (int kk = 0; kk < KA / 4; ++kk) af[kk] = Wa[(w * 16 + lr) * LD + kk * 4 + lk];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int kk = 0; kk < KA / 4; ++kk) bf[j][kk] = Xb[(j * 16 + lr) * LD + kk * 4 + lk];
-#pragma unroll
-  for (int kk = 0; kk < KA / 4; ++kk)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[j][kk], acc[j], 0, 0, 0);
+  for (int kk = 0; kk < Q; ++kk) af[kk] = Wa[(w * 16 + lr) * LD + kk * 4 + lk];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int f = f0 + w * 16 + lk + 4 * r;
-    if (f >= F) continue;
+    bv[r] = (f < F) ? b[f] : 0.0;
+  }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + j * 16 + lr;
-      if (n < N) store_through(Phi + (size_t)f * N + n, scale * rff_cos(acc[j][r]));
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = 2 * jh + jj;
+    double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < Q; ++kk)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], Xb[(j * 16 + lr) * LD + kk * 4 + lk], acc, 0, 0, 0);
+    const int n = n0 + j * 16 + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = f0 + w * 16 + lk + 4 * r;
+      if (f < F && n < N) store_through(Phi + (size_t)f * N + n, scale * rff_cos(acc[r] + bv[r]));
     }
   }
 }
@@ -258,7 +261,7 @@ int ppbo_rff_project(ppbo_ctx* ctx, const double* d_X, int N, int D, const doubl
   dim3 grid((N + TS - 1) / TS, (F + TS - 1) / TS);
   hipStream_t s = (hipStream_t)stream;
   PpboProfScope pf(ctx, ppbo_ctx::PF_RFF_PROJECT, s);
-#define RP_LAUNCH(DPV) rff_project_kernel<DPV><<<grid, 256, 0, s>>>(d_X, N, D, d_W, F, d_b, scale, d_Phi)
+#define RP_LAUNCH(DPV) rff_project_kernel<DPV><<<grid, 512, 0, s>>>(d_X, N, D, d_W, F, d_b, scale, d_Phi)
   if (D <= 4) RP_LAUNCH(4);
   else if (D <= 8) RP_LAUNCH(8);
   else if (D <= 12) RP_LAUNCH(12);

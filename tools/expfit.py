@@ -16,3 +16,20 @@ for deg in (10, 11, 12):
     print('   max rel', np.max(np.abs(p-ex)/ex)/2.22e-16, 'ulp')
     print('   coeffs', [x.hex() for x in cd])
     print('   ', cd)
+
+
+def sin_fit():
+    """Odd minimax polynomial for sin on [-pi/2, pi/2] (rff_cos in csrc/rff.hip): sin(r) = r * P(r^2)."""
+    a = (mp.pi / 2) ** 2 * mp.mpf('1.0002')
+
+    def g(z):
+        if z == 0:
+            return mp.mpf(1)
+        r = mp.sqrt(z)
+        return mp.sin(r) / r
+    c, err = mp.chebyfit(g, [0, a], 10, error=True)
+    print('sin: fit err', mp.nstr(err, 5), [float(x).hex() for x in c[::-1]])
+
+
+if __name__ == "__main__":
+    sin_fit()
