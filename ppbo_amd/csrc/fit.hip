@@ -440,7 +440,7 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
       }
       h_at_zero = false;
       ++nchol;
-      if (int rc = ppbo_potrf_async(ctx, W.H, N, N, W.d_info, s)) return rc;
+      if (int rc = ppbo_potrf_async(ctx, W.H, N, N, W.d_info, s, W.sc + 24)) return rc;
       int info = 0;
       PPBO_HIP_CHECK(ctx, hipMemcpyAsync(&info, W.d_info, sizeof(int), hipMemcpyDeviceToHost, s));
       PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
@@ -448,6 +448,15 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
       if (info != 0) {
         any_failed = true;
         lb = std::fmax(lb, lam);
+        // the failed pivot bounds the admissible shifts from below (as in SciPy's trust-exact): without it
+        // the bracket only learns "more than lam" and closes in on the pole by geometric means
+        if (ppbo_potrf_fail_bound_async(ctx, W.H, N, N, W.d_info, W.sc + 24, W.sc + 25, s) == 0) {
+          PPBO_HIP_CHECK(ctx, hipMemcpyAsync(W.hsc, W.sc + 25, sizeof(double), hipMemcpyDeviceToHost, s));
+          PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+          const double grow = W.hsc[0];
+          if (std::isfinite(grow) && grow > 0.0) lb = std::fmax(lb, lam + grow);
+          if (verbose > 1) printf("    [inner %d]   failed pivot: shift >= %.6e\n", inner, lam + grow);
+        }
         if (lb == 0.0) lb = 1e-14 * std::fmax(st_inf, 1e-300);   // lam = 0 is ruled out from now on
         if (ub <= lb) ub = 2.0 * lb + 1e-12;
         if (warm > lb && warm < ub) { lam = warm; warm = 0.0; }

@@ -20,7 +20,15 @@ struct GemmArgs {
 int ppbo_gemm_launch(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, hipStream_t s);
 
 // in-place lower Cholesky; d_info (device int) receives 0 or the failing 1-based column
-int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hipStream_t s);
+// d_fail_pivot (optional, device double): receives the non-positive pivot of a failed factorization
+// (only the default one-launch-per-step path writes it; callers pre-set it to NaN)
+int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hipStream_t s,
+                     double* d_fail_pivot = nullptr);
+// after a failure: d_out[0] = (-pivot) / |v|^2, the amount by which the shift must at least grow
+// (Conn/Gould/Toint 7.3; scipy.optimize._trustregion_exact.singular_leading_submatrix).  Returns 1 when
+// the bound is not available for this size.
+int ppbo_potrf_fail_bound_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, const int* d_info,
+                                const double* d_fail_pivot, double* d_out, hipStream_t s);
 // d_Linv (full N x N, upper part zeroed) = inverse of lower-triangular L
 int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d_Linv, int ldi, hipStream_t s);
 // y = T x (trans=0) or y = T^T x (trans=1) for a lower-triangular (lower=1) or full N x N matrix

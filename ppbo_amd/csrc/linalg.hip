@@ -251,7 +251,7 @@ constexpr int STEP_LDS = 82 * 1024;
 
 __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A, int lda, int N, int k0, int has_prev,
                                                          int nP, int ntS, double* __restrict__ diag_out,
-                                                         int* __restrict__ info) {
+                                                         int* __restrict__ info, double* __restrict__ fail_pivot) {
   extern __shared__ __attribute__((aligned(16))) double plds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lk = lane >> 4;
@@ -337,6 +337,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
   double* Xs = Li + 4 * 16 * 18;        // [4 waves][16][BLD] solve staging; until slab 0 is done: L[k, k-1] as [64][BLD]
   double* Rinv = Xs + 4 * 16 * BLD;     // [64] 1 / l_jj
   int& s_fail = *reinterpret_cast<int*>(Rinv + NB);
+  double& s_fpiv = Rinv[NB + 1];        // the non-positive pivot that stopped the factorization
   const int kb = (N - k0 < NB) ? (N - k0) : NB;
   // global reads, most urgent first (the counter retires them in order): diagonal block and L[k, k-1]
   // gate the factorization, the wave's own rows are not needed before slab 0 is under way
@@ -459,14 +460,14 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
 #pragma unroll
       for (int j = 0; j < 16; ++j) a[j] = Ab[lane * BLD + c0 + j];
       int fail = 0;
-      double rsv = 0.0;
+      double rsv = 0.0, fpiv = 0.0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         double v = a[j];
 #pragma unroll
         for (int k = 0; k < j; ++k) v -= a[k] * lane_bcast(a[k], c0 + j);
         const double d = lane_bcast(v, c0 + j);
-        if (!(d > 0.0) && fail == 0) fail = c0 + j + 1;
+        if (!(d > 0.0) && fail == 0) { fail = c0 + j + 1; fpiv = d; }
         const double rs = rsqrt_refined(d);
         a[j] = v * rs;
         rsv = (lane == c0 + j) ? rs : rsv;
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
         for (int j = 0; j < 16; ++j) Ab[lane * BLD + c0 + j] = (c0 + j <= lane) ? a[j] : 0.0;
         if (lane < c0 + 16) Rinv[lane] = rsv;
       }
-      if (fail && lane == 0 && s_fail == 0) s_fail = fail;
+      if (fail && lane == 0 && s_fail == 0) { s_fail = fail; s_fpiv = fpiv; }
     } else {
       if (s == 0 && has_prev) {
         // panel k-1's update of this wave's rows of block column k (L[k, k-1] is still staged in Xs)
@@ -520,25 +521,84 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
     else if (row0 < N) solve_block(2);
   }
   __syncthreads();
-  if (s_fail) {
-    if (blockIdx.x == 0 && t == 0) *info = k0 + s_fail;
-    return;
-  }
   if (blockIdx.x == 0) {
+    // also after a failure: the columns left of the failing one are final and the trust-region loop
+    // turns them into a lower bound on the shift (potrf_fail_bound_kernel)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int e = t + 256 * q;
       diag_out[e] = Ab[(e >> 6) * BLD + (e & 63)];
     }
+    if (s_fail && t == 0) {
+      *info = k0 + s_fail;
+      if (fail_pivot) *fail_pivot = s_fpiv;
+    }
   }
+  if (s_fail) return;
   if (row0 < N) solve_block(3);
+}
+
+// After a failed factorization of H + lam I at (0-based) column kf with pivot d <= 0, Conn/Gould/Toint's
+// (and SciPy trust-exact's `singular_leading_submatrix`) vector v = (-L1^-T l, 1, 0..), L1 = L[:kf, :kf],
+// l = L[kf, :kf], satisfies v'(H + lam I)v = d, hence every admissible shift is >= lam + (-d) / |v|^2.
+// One workgroup: back substitution with L1^T in 64-column blocks from the bottom up; the right-hand side
+// lives in LDS, each block's triangle is staged there too, the updates above it stream rows of L.
+// out[0] = (-d) / |v|^2  (NaN when the pivot itself was not finite).
+__global__ __launch_bounds__(256) void potrf_fail_bound_kernel(const double* __restrict__ L, int ldl,
+                                                               const int* __restrict__ info,
+                                                               const double* __restrict__ fail_pivot,
+                                                               double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double flds[];
+  double* Tb = flds;                 // [64][65] the current diagonal block of L
+  double* vb = Tb + 64 * 65;         // [64] solved entries of the block
+  double* red = vb + 64;             // [4] wave partials
+  double* rhs = red + 4;             // [kf] right-hand side / solution
+  const int kf = *info - 1;
+  const double d = *fail_pivot;
+  const int t = threadIdx.x;
+  if (kf < 0) { if (t == 0) out[0] = NAN; return; }
+  for (int i = t; i < kf; i += 256) rhs[i] = -L[(size_t)kf * ldl + i];
+  __syncthreads();
+  double vn2 = 0.0;                  // thread-local share of |v1|^2
+  for (int b1 = kf; b1 > 0; b1 -= 64) {
+    const int b0 = (b1 >= 64) ? b1 - 64 : 0, nb = b1 - b0;
+    for (int e = t; e < nb * nb; e += 256) {
+      const int r = e / nb, c = e - r * nb;
+      Tb[r * 65 + c] = (c <= r) ? L[(size_t)(b0 + r) * ldl + b0 + c] : 0.0;
+    }
+    __syncthreads();
+    if (t < 64) {
+      // U x = r with U = Tb^T: lane i owns r_i; columns from the last to the first
+      double ri = (t < nb) ? rhs[b0 + t] : 0.0;
+      for (int j = nb - 1; j >= 0; --j) {
+        const double xj = __shfl(ri, j, 64) / Tb[j * 65 + j];
+        if (t == j) ri = xj;
+        else if (t < j) ri -= Tb[j * 65 + t] * xj;
+      }
+      if (t < nb) { vb[t] = ri; rhs[b0 + t] = ri; vn2 += ri * ri; }
+    }
+    __syncthreads();
+    // rows above the block: r_i -= sum_j L[b0+j][i] x_j
+    for (int i = t; i < b0; i += 256) {
+      double acc = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < nb; ++j) acc += L[(size_t)(b0 + j) * ldl + i] * vb[j];
+      rhs[i] -= acc;
+    }
+    __syncthreads();
+  }
+  vn2 = wave_sum(vn2);
+  if ((t & 63) == 0) red[t >> 6] = vn2;
+  __syncthreads();
+  if (t == 0) out[0] = (-d) / (1.0 + ((red[0] + red[1]) + (red[2] + red[3])));
 }
 
 // diagonal factors parked by potrf_step_kernel -> lower triangles of A's diagonal blocks
 __global__ __launch_bounds__(256) void scatter_diag_kernel(double* __restrict__ A, int lda, int N,
                                                            const double* __restrict__ diag, const int* __restrict__ info) {
-  if (*info != 0) return;
+  const int bad = *info;                       // 1-based failing column, 0 = success
   const int k0 = blockIdx.x * NB;
+  if (bad != 0 && k0 >= bad) return;           // panels right of the failure were never factored
   const double* src = diag + (size_t)blockIdx.x * NB * NB;
   for (int e = threadIdx.x; e < NB * NB; e += 256) {
     const int r = e / NB, c = e - r * NB;
@@ -711,7 +771,10 @@ __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x,
   }
 }
 
-__global__ void set_int_kernel(int* p, int v) { *p = v; }
+__global__ void set_int_kernel(int* p, int v, double* fail_pivot) {
+  *p = v;
+  if (fail_pivot) *fail_pivot = NAN;
+}
 
 }  // namespace
 
@@ -722,9 +785,9 @@ static int potrf_gen() {
   return g;
 }
 
-int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hipStream_t s) {
+int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hipStream_t s, double* d_fail_pivot) {
   PpboProfScope pf(ctx, ppbo_ctx::PF_POTRF, s);
-  set_int_kernel<<<1, 1, 0, s>>>(d_info, 0);
+  set_int_kernel<<<1, 1, 0, s>>>(d_info, 0, d_fail_pivot);
   if (potrf_gen() >= 3) {
     static bool attr_done = false;
     if (!attr_done) {
@@ -741,7 +804,7 @@ int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hi
       const int nS = ntS ? (ntS + 1) * ((ntS + 1) / 2) : 0;
       const int nSW = nS < 256 - nP ? nS : 256 - nP;   // one workgroup per CU (STEP_LDS), the update part is persistent
       potrf_step_kernel<<<nP + nSW, 256, STEP_LDS, s>>>(d_A, lda, N, k0, k0 > 0 ? 1 : 0, nP, ntS,
-                                                        diag + (size_t)(k0 / NB) * NB * NB, d_info);
+                                                        diag + (size_t)(k0 / NB) * NB * NB, d_info, d_fail_pivot);
     }
     scatter_diag_kernel<<<npanel, 256, 0, s>>>(d_A, lda, N, diag, d_info);
     PPBO_LAUNCH_CHECK(ctx);
@@ -762,6 +825,20 @@ int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hi
       if (int rc = ppbo_gemm_launch(ctx, g, 0, 1, s)) return rc;
     }
   }
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int ppbo_potrf_fail_bound_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, const int* d_info,
+                                const double* d_fail_pivot, double* d_out, hipStream_t s) {
+  const size_t lds = ((size_t)64 * 65 + 64 + 4 + N) * sizeof(double);
+  if (lds > 150 * 1024) return 1;     // leading block too large for the LDS-resident right-hand side: no bound
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)potrf_fail_bound_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_done = true;
+  }
+  potrf_fail_bound_kernel<<<1, 256, lds, s>>>(d_L, ldl, d_info, d_fail_pivot, d_out);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
