@@ -551,7 +551,10 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
     prev_lam = lam_used;
     prev_radius = radius;
     prev_boundary = boundary;
-    prev_failed = any_failed;
+    // indefiniteness is sticky: H changes little between iterates, so once a factorization at (or near) lam = 0
+    // has failed the warm multiplier goes first until an interior Newton step is accepted again
+    if (any_failed) prev_failed = true;
+    else if (!boundary) prev_failed = false;
     // (H + lam I) p = -g  =>  p'Hp = -g'p - lam |p|^2
     const double pred = used_hard ? hard_pred : (-0.5 * gtp + 0.5 * lam_used * pn * pn);
     if (!(pred > 0.0)) break;
