@@ -230,102 +230,95 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
   }
 }
 
-// ---- ONE launch per panel step, with one step of lookahead.
-// Launch k holds two independent kinds of workgroup:
-//   panel part (the first nP workgroups, one per 48 rows below the panel): first applies panel k-1's
-//     rank-64 update to block column k only (its own 48 rows and, redundantly, the diagonal block), then
-//     factors the diagonal block ITSELF -- the factor never travels between workgroups, the redundant
-//     flops are free on <= 42 of 256 CUs -- and solves its 48 rows against it.  Nobody may overwrite A_kk
-//     while another workgroup can still be reading it, so workgroup 0 parks L_kk in a side buffer
-//     (diag_out, one 64x64 slot per panel) that scatter_diag_kernel copies back once at the end;
-//   update part (the remaining workgroups, persistent over the 64x64 tiles): panel k-1's trailing update
-//     on block columns >= k+1, i.e. everything the panel part does not touch.
-// Block column k therefore meets panel k-1's update one launch late, inside the panel part, and the
-// bulk trailing update runs in the shadow of the latency-bound panel instead of after it: a step costs
-// max(panel, update) and one launch instead of panel + update and two.  No workgroup reads what another
-// one writes in the same launch: the panel part reads columns k-1 and k and writes column k (the diagonal
-// factor to the side buffer), the update part reads column k-1 and read-modify-writes columns >= k+1.
-// More than half of the CU's 160 KB: exactly one workgroup per CU, so a panel workgroup never shares its SIMDs
-// with MFMA-saturated update workgroups (measured: sharing stretches the panel part from 23.5 to 30.5 us).
-constexpr int STEP_LDS = 82 * 1024;
+// One launch per panel step, update part: C -= P P^T with P = block column k-1, on the tiles right of block
+// column k.  Persistent: a workgroup walks the folded tile list; the next tile's operands and C values are
+// requested before the current tile's MFMAs, so a tile costs its 64 MFMAs per wavefront, not a memory round
+// trip.  rank / r0: this workgroup's slot in the round-robin (see tile_of) and its first round.
+constexpr int PANEL_ROUNDS = 6;
 
-__global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A, int lda, int N, int k0, int has_prev,
-                                                         int nP, int ntS, double* __restrict__ diag_out,
-                                                         int* __restrict__ info, double* __restrict__ fail_pivot) {
-  extern __shared__ __attribute__((aligned(16))) double plds[];
+__device__ __forceinline__ void potrf_update_part(double* __restrict__ A, int lda, int N, int k0, int nP, int ntS,
+                                                  double* __restrict__ plds, int rank, int r0) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  const int info_in = *info;
-  if ((int)blockIdx.x >= nP) {
-    // ------------------------------------------------ update part: C -= P P^T, P = block column k-1
-    // Persistent: gridDim.x - nP workgroups (one per remaining CU) stride over the folded tile list; the
-    // next tile's operands and C values are requested before the current tile's MFMAs, so a tile costs its
-    // 64 MFMAs per wavefront, not a memory round trip.
-    if (info_in != 0) return;
-    double* Pi = plds;
-    double* Pj = plds + NB * BLD;
-    const int kp = k0 - NB, cs = k0 + NB;
-    const int nSW = gridDim.x - nP, total = (ntS + 1) * ((ntS + 1) / 2);
-    double pi[16], pj[16];
-    double4_t accN[4];
-    int ti = 0, tj = 0;
-    bool valid = false;
-    auto fetch = [&](int idx) {
-      const int c = idx % (ntS + 1), tr = idx / (ntS + 1);
-      if (c <= tr) { ti = tr; tj = c; valid = true; }
-      else { ti = ntS - 1 - tr; tj = c - tr - 1; valid = (ti != tr); }
-      const int i0 = cs + ti * NB, j0 = cs + tj * NB;
+  double* Pi = plds;
+  double* Pj = plds + NB * BLD;
+  const int kp = k0 - NB, cs = k0 + NB;
+  const int nSW = gridDim.x - nP, total = (ntS + 1) * ((ntS + 1) / 2);
+  // round r hands out nSW tiles to the update workgroups and, from round PANEL_ROUNDS on, nP more to the
+  // panel workgroups, which join once their panel is done (a panel takes about as long as six tiles)
+  auto tile_of = [&](int r) { return r * nSW + (r > PANEL_ROUNDS ? (r - PANEL_ROUNDS) * nP : 0) + rank; };
+  double pi[16], pj[16];
+  double4_t accN[4];
+  int ti = 0, tj = 0;
+  bool valid = false;
+  auto fetch = [&](int idx) {
+    const int c = idx % (ntS + 1), tr = idx / (ntS + 1);
+    if (c <= tr) { ti = tr; tj = c; valid = true; }
+    else { ti = ntS - 1 - tr; tj = c - tr - 1; valid = (ti != tr); }
+    const int i0 = cs + ti * NB, j0 = cs + tj * NB;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int e = t + 256 * q, r = e >> 6, cc = e & 63;
-        pi[q] = (valid && i0 + r < N) ? A[(size_t)(i0 + r) * lda + kp + cc] : 0.0;
-        pj[q] = (valid && ti != tj && j0 + r < N) ? A[(size_t)(j0 + r) * lda + kp + cc] : 0.0;
+    for (int q = 0; q < 16; ++q) {
+      const int e = t + 256 * q, r = e >> 6, cc = e & 63;
+      pi[q] = (valid && i0 + r < N) ? A[(size_t)(i0 + r) * lda + kp + cc] : 0.0;
+      pj[q] = (valid && ti != tj && j0 + r < N) ? A[(size_t)(j0 + r) * lda + kp + cc] : 0.0;
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gr = i0 + 16 * wave + lk + 4 * r, gc = j0 + 16 * jt + lr;
+        accN[jt][r] = (valid && gr < N && gc < N) ? A[(size_t)gr * lda + gc] : 0.0;
+      }
+  };
+  int rnd = r0;
+  int cur = tile_of(rnd);
+  if (cur < total) fetch(cur);
+  for (; cur < total;) {
+    const int nxt = tile_of(rnd + 1);
+    const bool v_cur = valid, diag_cur = (ti == tj);
+    const int i0 = cs + ti * NB, j0 = cs + tj * NB;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = t + 256 * q;
+      Pi[(e >> 6) * BLD + (e & 63)] = pi[q];
+      if (!diag_cur) Pj[(e >> 6) * BLD + (e & 63)] = pj[q];
+    }
+    double4_t acc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) acc[jt] = accN[jt];
+    __syncthreads();
+    if (nxt < total) fetch(nxt);
+    if (v_cur) {
+      const double* Pb = diag_cur ? Pi : Pj;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const double av = -Pi[(16 * wave + lr) * BLD + 4 * kk + lk];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+          acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pb[(16 * jt + lr) * BLD + 4 * kk + lk], acc[jt], 0, 0, 0);
       }
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int gr = i0 + 16 * wave + lk + 4 * r, gc = j0 + 16 * jt + lr;
-          accN[jt][r] = (valid && gr < N && gc < N) ? A[(size_t)gr * lda + gc] : 0.0;
+          if (gr < N && gc < N) store_through(A + (size_t)gr * lda + gc, acc[jt][r]);
         }
-    };
-    int cur = blockIdx.x - nP;
-    if (cur < total) fetch(cur);
-    for (; cur < total; cur += nSW) {
-      const bool v_cur = valid, diag_cur = (ti == tj);
-      const int i0 = cs + ti * NB, j0 = cs + tj * NB;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int e = t + 256 * q;
-        Pi[(e >> 6) * BLD + (e & 63)] = pi[q];
-        if (!diag_cur) Pj[(e >> 6) * BLD + (e & 63)] = pj[q];
-      }
-      double4_t acc[4];
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) acc[jt] = accN[jt];
-      __syncthreads();
-      if (cur + nSW < total) fetch(cur + nSW);
-      if (v_cur) {
-        const double* Pb = diag_cur ? Pi : Pj;
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          const double av = -Pi[(16 * wave + lr) * BLD + 4 * kk + lk];
-#pragma unroll
-          for (int jt = 0; jt < 4; ++jt)
-            acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pb[(16 * jt + lr) * BLD + 4 * kk + lk], acc[jt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int gr = i0 + 16 * wave + lk + 4 * r, gc = j0 + 16 * jt + lr;
-            if (gr < N && gc < N) store_through(A + (size_t)gr * lda + gc, acc[jt][r]);
-          }
-      }
-      __syncthreads();
     }
-    return;
+    __syncthreads();
+    cur = nxt;
+    ++rnd;
   }
+}
+
+// One launch per panel step, panel part (see potrf_step_kernel).  Returns false when the factorization has
+// failed (here or earlier) and the workgroup has nothing more to do.
+__device__ __forceinline__ bool potrf_panel_part(double* __restrict__ A, int lda, int N, int k0, int has_prev,
+                                                 double* __restrict__ diag_out, int* __restrict__ info,
+                                                 double* __restrict__ fail_pivot, double* __restrict__ plds,
+                                                 int info_in) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
   // -------------------------------------------------- panel part
   // Wave 0 only factors; waves 1-3 own 16 panel rows each (48 rows per workgroup) and fill the time wave 0
   // spends inside a slab (~2.2 us, waves 1-3 would otherwise idle at the barrier):
@@ -368,7 +361,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
       const int gr = row0 + lk + 4 * r;
       rowv[c][r] = (gr < N) ? A[(size_t)gr * lda + k0 + 16 * c + lr] : 0.0;
     }
-  if (info_in != 0) return;
+  if (info_in != 0) return false;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int e = t + 256 * q;
@@ -534,8 +527,47 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
       if (fail_pivot) *fail_pivot = s_fpiv;
     }
   }
-  if (s_fail) return;
+  if (s_fail) return false;
   if (row0 < N) solve_block(3);
+  return true;
+}
+
+// ---- ONE launch per panel step, with one step of lookahead.
+// Launch k holds two independent kinds of workgroup:
+//   panel part (the first nP workgroups, one per 48 rows below the panel): first applies panel k-1's
+//     rank-64 update to block column k only (its own 48 rows and, redundantly, the diagonal block), then
+//     factors the diagonal block ITSELF -- the factor never travels between workgroups, the redundant
+//     flops are free on <= 42 of 256 CUs -- and solves its 48 rows against it.  Nobody may overwrite A_kk
+//     while another workgroup can still be reading it, so workgroup 0 parks L_kk in a side buffer
+//     (diag_out, one 64x64 slot per panel) that scatter_diag_kernel copies back once at the end;
+//   update part (the remaining workgroups, persistent over the 64x64 tiles): panel k-1's trailing update
+//     on block columns >= k+1, i.e. everything the panel part does not touch.
+// Block column k therefore meets panel k-1's update one launch late, inside the panel part, and the
+// bulk trailing update runs in the shadow of the latency-bound panel instead of after it: a step costs
+// max(panel, update) and one launch instead of panel + update and two.  No workgroup reads what another
+// one writes in the same launch: the panel part reads columns k-1 and k and writes column k (the diagonal
+// factor to the side buffer), the update part reads column k-1 and read-modify-writes columns >= k+1.
+// More than half of the CU's 160 KB: exactly one workgroup per CU, so a panel workgroup never shares its SIMDs
+// with MFMA-saturated update workgroups (measured: sharing stretches the panel part from 23.5 to 30.5 us).
+constexpr int STEP_LDS = 82 * 1024;
+constexpr int STEP_LDS_SHARED = (NB * BLD + 4 * 16 * 18 + 4 * 16 * BLD + NB + 2) * (int)sizeof(double);   // what the panel part needs: two per CU
+
+__global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A, int lda, int N, int k0, int has_prev,
+                                                         int nP, int ntS, double* __restrict__ diag_out,
+                                                         int* __restrict__ info, double* __restrict__ fail_pivot) {
+  extern __shared__ __attribute__((aligned(16))) double plds[];
+  const int info_in = *info;
+  if (info_in != 0) return;
+  const int nSW = gridDim.x - nP;
+  if ((int)blockIdx.x >= nP) {
+    potrf_update_part(A, lda, N, k0, nP, ntS, plds, blockIdx.x - nP, 0);
+    return;
+  }
+  if (!potrf_panel_part(A, lda, N, k0, has_prev, diag_out, info, fail_pivot, plds, info_in)) return;
+  // the panel is done; help with the trailing update (the tile lists of the rounds >= PANEL_ROUNDS)
+  if (ntS == 0 || PANEL_ROUNDS * nSW >= (ntS + 1) * ((ntS + 1) / 2)) return;
+  __syncthreads();
+  potrf_update_part(A, lda, N, k0, nP, ntS, plds, nSW + blockIdx.x, PANEL_ROUNDS);
 }
 
 // After a failed factorization of H + lam I at (0-based) column kf with pivot d <= 0, Conn/Gould/Toint's
@@ -802,8 +834,14 @@ int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hi
       const int nP = rest > 0 ? (rest + 47) / 48 : 1;   // panel part: 3 row-owning wavefronts of 16 rows
       const int ntS = (k0 > 0 && rest > 0) ? (rest + NB - 1) / NB : 0;
       const int nS = ntS ? (ntS + 1) * ((ntS + 1) / 2) : 0;
-      const int nSW = nS < 256 - nP ? nS : 256 - nP;   // one workgroup per CU (STEP_LDS), the update part is persistent
-      potrf_step_kernel<<<nP + nSW, 256, STEP_LDS, s>>>(d_A, lda, N, k0, k0 > 0 ? 1 : 0, nP, ntS,
+      // One workgroup per CU (STEP_LDS) keeps the panel undisturbed; when the trailing update is so large that
+      // it, not the panel, sets the step time (N >= ~3000), two workgroups share a CU instead: the panel slows
+      // down by a third, the update nearly doubles its rate (a lone update workgroup is bound by the latency
+      // of its one-tile-ahead prefetch).
+      const bool crowded = nS > 900;
+      const int slots = (crowded ? 512 : 256) - nP;
+      const int nSW = nS < slots ? nS : slots;
+      potrf_step_kernel<<<nP + nSW, 256, crowded ? STEP_LDS_SHARED : STEP_LDS, s>>>(d_A, lda, N, k0, k0 > 0 ? 1 : 0, nP, ntS,
                                                         diag + (size_t)(k0 / NB) * NB * NB, d_info, d_fail_pivot);
     }
     scatter_diag_kernel<<<npanel, 256, 0, s>>>(d_A, lda, N, diag, d_info);
