@@ -267,7 +267,7 @@ struct FitWork {
   int N, m, mblk, n_q;
   double sigma;
   double *H, *Linv;       // N x N each
-  double *tq, *rowstats, *sc, *u, *w, *p, *q;
+  double *tq, *rowstats, *sc, *u, *w, *p, *q, *tmpv;
   double* hsc;            // pinned host scalars
   int* d_info;
 };
@@ -297,14 +297,14 @@ int carve_fit_work(ppbo_ctx* ctx, FitWork& W, Vecs* pts, int npts) {
   W.H = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG, 2 * nn * sizeof(double));
   if (!W.H) return (int)hipErrorOutOfMemory;
   W.Linv = W.H + nn;
-  const size_t nvec = (size_t)npts * 6 + 4 + 3 + 1;
+  const size_t nvec = (size_t)npts * 6 + 5 + 3 + 1;
   double* v = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SCRATCH, (nvec * N + W.n_q + 64) * sizeof(double) + 256);
   if (!v) return (int)hipErrorOutOfMemory;
   for (int k = 0; k < npts; ++k) {
     pts[k].f = v; v += N; pts[k].v = v; v += N; pts[k].beta = v; v += N;
     pts[k].ld = v; v += N; pts[k].lo = v; v += N; pts[k].g = v; v += N;
   }
-  W.u = v; v += N; W.w = v; v += N; W.p = v; v += N; W.q = v; v += N;
+  W.u = v; v += N; W.w = v; v += N; W.p = v; v += N; W.q = v; v += N; W.tmpv = v; v += N;
   W.rowstats = v; v += 3 * (size_t)N;
   W.tq = v; v += W.n_q;
   W.sc = v; v += 32;
@@ -467,11 +467,15 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
         continue;
       }
       best_pd = std::fmin(best_pd, lam);
-      if (int rc = ppbo_trtri_async(ctx, W.H, N, N, W.Linv, N, s)) return rc;
-      if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, C.g, W.w, 0, 1, s)) return rc;   // w = L^-1 g
-      if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.w, W.u, 1, 1, s)) return rc;   // u = L^-T w
+      int split = 0;     // L^-1 is kept as two diagonal blocks + L21 (ppbo_apply_linv_async)
+      if (int rc = ppbo_trtri_async(ctx, W.H, N, N, W.Linv, N, s, 1, &split)) return rc;
+      auto apply_linv = [&](const double* x, double* y, int trans) {
+        return ppbo_apply_linv_async(ctx, W.Linv, N, W.H, N, N, split, x, y, trans, W.tmpv, s);
+      };
+      if (int rc = apply_linv(C.g, W.w, 0)) return rc;   // w = L^-1 g
+      if (int rc = apply_linv(W.w, W.u, 1)) return rc;   // u = L^-T w
       step_kernel<<<1, 1024, 0, s>>>(W.u, C.g, C.f, N, W.p, T.f, W.sc + 16);           // p = -u, fn = f + p
-      if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.p, W.q, 0, 1, s)) return rc;   // q = L^-1 p
+      if (int rc = apply_linv(W.p, W.q, 0)) return rc;   // q = L^-1 p
       if (int rc = ppbo_dot_async(ctx, W.q, W.q, N, W.sc + 18, s)) return rc;
       PPBO_HIP_CHECK(ctx, hipMemcpyAsync(W.hsc, W.sc + 16, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
       PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
@@ -493,10 +497,10 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
         // of the smallest eigenvalue s2 of H + lam I; p + tau z on the boundary is accepted when it changes the
         // model by less than k_hard, and lam - s2 is a tight lower bound on the admissible shifts.
         std::vector<double>& hp = host_p; std::vector<double>& hz = host_z; std::vector<double>& hl = host_lz;
-        if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.p, W.w, 0, 1, s)) return rc;
-        if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.w, W.u, 1, 1, s)) return rc;
-        if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.u, W.w, 0, 1, s)) return rc;
-        if (int rc = ppbo_gemv_async(ctx, W.Linv, N, N, W.w, W.u, 1, 1, s)) return rc;      // u ~ eigenvector
+        if (int rc = apply_linv(W.p, W.w, 0)) return rc;
+        if (int rc = apply_linv(W.w, W.u, 1)) return rc;
+        if (int rc = apply_linv(W.u, W.w, 0)) return rc;
+        if (int rc = apply_linv(W.w, W.u, 1)) return rc;      // u ~ eigenvector
         if (int rc = ppbo_gemv_async(ctx, W.H, N, N, W.u, W.q, 1, 1, s)) return rc;         // q = L^T u
         PPBO_HIP_CHECK(ctx, hipMemcpyAsync(hp.data(), W.p, vbytes, hipMemcpyDeviceToHost, s));
         PPBO_HIP_CHECK(ctx, hipMemcpyAsync(hz.data(), W.u, vbytes, hipMemcpyDeviceToHost, s));

@@ -30,7 +30,12 @@ int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hi
 int ppbo_potrf_fail_bound_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, const int* d_info,
                                 const double* d_fail_pivot, double* d_out, hipStream_t s);
 // d_Linv (full N x N, upper part zeroed) = inverse of lower-triangular L
-int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d_Linv, int ldi, hipStream_t s);
+// skip_top: leave the last doubling level (the split [0, b) | [b, N), b the largest 64 * 2^k < N) unformed and
+// report b in *split_out; the result is then applied with ppbo_apply_linv_async
+int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d_Linv, int ldi, hipStream_t s,
+                     int skip_top = 0, int* split_out = nullptr);
+int ppbo_apply_linv_async(ppbo_ctx* ctx, const double* d_Linv, int ldi, const double* d_L, int ldl, int N, int split,
+                          const double* d_x, double* d_y, int trans, double* d_tmp, hipStream_t s);
 // y = T x (trans=0) or y = T^T x (trans=1) for a lower-triangular (lower=1) or full N x N matrix
 int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const double* d_x, double* d_y, int trans,
                     int lower, hipStream_t s);

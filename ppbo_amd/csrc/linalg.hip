@@ -714,13 +714,13 @@ __global__ __launch_bounds__(256) void trtri_diag_kernel(const double* __restric
 }
 
 // y = T x, one wavefront per row
-__global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ T, int N, int ldt,
-                                                        const double* __restrict__ x, double* __restrict__ y,
-                                                        int lower) {
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ T, int rows, int cols, int ldt,
+                                                        const double* __restrict__ x, const double* __restrict__ y0,
+                                                        double* __restrict__ y, int lower) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= N) return;
-  const int kend = lower ? (i + 1) : N;
+  if (i >= rows) return;
+  const int kend = (lower && i + 1 < cols) ? (i + 1) : cols;
   const double* row = T + (size_t)i * ldt;
   double s = 0.0;
   const bool vec = ((ldt & 1) == 0) && ((reinterpret_cast<uintptr_t>(T) & 15) == 0) &&
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
     for (int k = lane; k < kend; k += 64) s += row[k] * x[k];
   }
   s = wave_sum(s);
-  if (lane == 0) y[i] = s;
+  if (lane == 0) y[i] = y0 ? y0[i] - s : s;
 }
 
 // y = T^T x in two deterministic passes.  partial[split][j] = sum_{i in split, i >= (lower ? j : 0)} T[i][j] x[i]
@@ -746,28 +746,29 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
 // passes.
 constexpr int GT_ROWS = 16;
 
-__global__ __launch_bounds__(256) void gemvT_partial_kernel(const double* __restrict__ T, int N, int ldt,
+__global__ __launch_bounds__(256) void gemvT_partial_kernel(const double* __restrict__ T, int rows, int cols, int ldt,
                                                             const double* __restrict__ x,
                                                             double* __restrict__ partial, int lower) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int i0 = blockIdx.y * GT_ROWS;
   if (lower && i0 + GT_ROWS <= (int)blockIdx.x * 256) return;      // no row of this split reaches these columns
-  if (j >= N) return;
+  if (j >= cols) return;
   double v[GT_ROWS];
 #pragma unroll
   for (int r = 0; r < GT_ROWS; ++r) {
     const int i = i0 + r;
-    v[r] = (i < N && (!lower || i >= j)) ? T[(size_t)i * ldt + j] : 0.0;
+    v[r] = (i < rows && (!lower || i >= j)) ? T[(size_t)i * ldt + j] : 0.0;
   }
   double s = 0.0;
 #pragma unroll
-  for (int r = 0; r < GT_ROWS; ++r) s += v[r] * ((i0 + r < N) ? x[i0 + r] : 0.0);
-  partial[(size_t)blockIdx.y * N + j] = s;
+  for (int r = 0; r < GT_ROWS; ++r) s += v[r] * ((i0 + r < rows) ? x[i0 + r] : 0.0);
+  partial[(size_t)blockIdx.y * cols + j] = s;
 }
 
 // y[j] = sum over the splits that were written; 16 columns x 16 split groups per workgroup, fixed summation order
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const double* __restrict__ partial, int n_split, int N,
-                                                        double* __restrict__ y, int lower) {
+                                                        const double* __restrict__ y0, double* __restrict__ y,
+                                                        int lower) {
   __shared__ double sh[16][17];
   const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + c;
@@ -784,7 +785,7 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const double* __restrict
     double t = 0.0;
 #pragma unroll
     for (int g = 0; g < 16; ++g) t += sh[g][c];
-    y[j] = t;
+    y[j] = y0 ? y0[j] - t : t;
   }
 }
 
@@ -881,7 +882,9 @@ int ppbo_potrf_fail_bound_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl
   return 0;
 }
 
-int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d_Linv, int ldi, hipStream_t s) {
+int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d_Linv, int ldi, hipStream_t s,
+                     int skip_top, int* split_out) {
+  if (split_out) *split_out = 0;
   PPBO_HIP_CHECK(ctx, hipMemsetAsync(d_Linv, 0, (size_t)N * ldi * sizeof(double), s));
   const int nblk = (N + NB - 1) / NB;
   trtri_diag_kernel<<<nblk, 256, 0, s>>>(d_L, ldl, N, d_Linv, ldi);
@@ -890,6 +893,10 @@ int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d
   double* Tw = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG2, (size_t)N * N / 2 * sizeof(double) + 4096);
   if (!Tw) return (int)hipErrorOutOfMemory;
   for (int b = NB; b < N; b *= 2) {
+    if (skip_top && 2 * b >= N) {       // the top split [0, b) | [b, N) stays implicit (ppbo_apply_linv_async)
+      if (split_out) *split_out = b;
+      break;
+    }
     const int step = 2 * b;
     int nfull = 0;
     int ragged_r0 = -1, ragged_b2 = 0;
@@ -930,19 +937,46 @@ int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d
   return 0;
 }
 
-int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const double* d_x, double* d_y, int trans,
-                    int lower, hipStream_t s) {
+// y = T x (trans = 0, T rows x cols) or y = T^T x (trans = 1); with y0: y = y0 - (that product)
+int ppbo_gemv_rect_async(ppbo_ctx* ctx, const double* d_T, int rows, int cols, int ldt, const double* d_x,
+                         const double* d_y0, double* d_y, int trans, int lower, hipStream_t s) {
   if (!trans) {
-    gemv_rows_kernel<<<(N + 3) / 4, 256, 0, s>>>(d_T, N, ldt, d_x, d_y, lower);
+    gemv_rows_kernel<<<(rows + 3) / 4, 256, 0, s>>>(d_T, rows, cols, ldt, d_x, d_y0, d_y, lower);
   } else {
-    const int n_split = (N + GT_ROWS - 1) / GT_ROWS;
-    double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, (size_t)n_split * N * sizeof(double));
+    const int n_split = (rows + GT_ROWS - 1) / GT_ROWS;
+    double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, (size_t)n_split * cols * sizeof(double));
     if (!part) return (int)hipErrorOutOfMemory;
-    gemvT_partial_kernel<<<dim3((N + 255) / 256, n_split), 256, 0, s>>>(d_T, N, ldt, d_x, part, lower);
-    sum_slabs_kernel<<<(N + 15) / 16, 256, 0, s>>>(part, n_split, N, d_y, lower);
+    gemvT_partial_kernel<<<dim3((cols + 255) / 256, n_split), 256, 0, s>>>(d_T, rows, cols, ldt, d_x, part, lower);
+    sum_slabs_kernel<<<(cols + 15) / 16, 256, 0, s>>>(part, n_split, cols, d_y0, d_y, lower);
   }
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
+}
+
+int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const double* d_x, double* d_y, int trans,
+                    int lower, hipStream_t s) {
+  return ppbo_gemv_rect_async(ctx, d_T, N, N, ldt, d_x, nullptr, d_y, trans, lower, s);
+}
+
+// y = L^-1 x / y = L^-T x with the inverse held as ppbo_trtri_async(skip_top = 1) leaves it: the two diagonal
+// blocks W11 = inv(L11) ([0, split)) and W22 = inv(L22), the coupling applied through L21 itself:
+//   L^-1 x = ( W11 x1 , W22 (x2 - L21 W11 x1) ),   L^-T x = ( W11^T (x1 - L21^T W22^T x2) , W22^T x2 ).
+// Same bytes as one GEMV with the full inverse, two more launches, and the two largest GEMMs of the
+// inversion (half its time) are never run.  d_tmp: N doubles of scratch.
+int ppbo_apply_linv_async(ppbo_ctx* ctx, const double* d_Linv, int ldi, const double* d_L, int ldl, int N, int split,
+                          const double* d_x, double* d_y, int trans, double* d_tmp, hipStream_t s) {
+  if (split <= 0 || split >= N) return ppbo_gemv_async(ctx, d_Linv, N, ldi, d_x, d_y, trans, 1, s);
+  const int n2 = N - split;
+  const double* W22 = d_Linv + (size_t)split * ldi + split;
+  const double* L21 = d_L + (size_t)split * ldl;
+  if (!trans) {
+    if (int rc = ppbo_gemv_rect_async(ctx, d_Linv, split, split, ldi, d_x, nullptr, d_y, 0, 1, s)) return rc;
+    if (int rc = ppbo_gemv_rect_async(ctx, L21, n2, split, ldl, d_y, d_x + split, d_tmp, 0, 0, s)) return rc;
+    return ppbo_gemv_rect_async(ctx, W22, n2, n2, ldi, d_tmp, nullptr, d_y + split, 0, 1, s);
+  }
+  if (int rc = ppbo_gemv_rect_async(ctx, W22, n2, n2, ldi, d_x + split, nullptr, d_y + split, 1, 1, s)) return rc;
+  if (int rc = ppbo_gemv_rect_async(ctx, L21, n2, split, ldl, d_y + split, d_x, d_tmp, 1, 0, s)) return rc;
+  return ppbo_gemv_rect_async(ctx, d_Linv, split, split, ldi, d_tmp, nullptr, d_y, 1, 1, s);
 }
 
 int ppbo_dot_async(ppbo_ctx* ctx, const double* d_x, const double* d_y, int N, double* d_out, hipStream_t s) {
