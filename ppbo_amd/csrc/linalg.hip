@@ -319,7 +319,6 @@ __device__ __forceinline__ bool potrf_panel_part(double* __restrict__ A, int lda
                                                  int info_in) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  // -------------------------------------------------- panel part
   // Wave 0 only factors; waves 1-3 own 16 panel rows each (48 rows per workgroup) and fill the time wave 0
   // spends inside a slab (~2.2 us, waves 1-3 would otherwise idle at the barrier):
   //   during slab 0   panel k-1's update of their own rows
