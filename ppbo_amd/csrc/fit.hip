@@ -394,6 +394,11 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
   double st_mindiag = 0, st_gmax = 0, st_gmin = 0, st_fro = 0, st_inf = 0;
   int it = 0, nchol = 0;
   bool h_at_zero = false;  // H buffer currently holds the unfactorized lam=0 matrix
+  // Chord steps: after an interior Newton step that the model predicted well, the next iterate(s) reuse the
+  // factor (and its inverse blocks) instead of refactoring -- near the optimum the Hessian barely moves, a chord
+  // step costs two triangular applications instead of a Cholesky + inversion, and the step is still judged by
+  // the same actual/predicted ratio (the model is then the quadratic with the OLD Hessian).
+  int chord_left = 0, split = 0;
 
   if (!std::isfinite(pt[cur].gn2) || !std::isfinite(pt[cur].fSf))
     return ppbo_set_error(ctx, -3, "non-finite objective at the start vector");
@@ -402,7 +407,7 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
     Vecs& C = pt[cur];
     Vecs& T = pt[cur ^ 1];
     const double gnorm = std::sqrt(C.gn2);
-    if (h_changed) {
+    if (h_changed && chord_left == 0) {
       form_shifted_kernel<<<N, 256, 0, s>>>(W.Sinv, N, W.mblk, C.ld, C.lo, 0.0, W.H, W.rowstats);
       stats_reduce_kernel<<<1, 1024, 0, s>>>(W.rowstats, N, W.sc + 8);
       PPBO_LAUNCH_CHECK(ctx);
@@ -433,7 +438,11 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
     bool boundary = true, have_step = false, used_hard = false;
     double pn = 0.0, gtp = 0.0, lam_used = 0.0, hard_pred = 0.0;
     host_g_valid = false;
+    bool chord = (chord_left > 0);
+    if (chord) lam = 0.0;
+    bool chord_abort = false;
     for (int inner = 0; inner < 80; ++inner) {
+      if (!chord) {
       if (!(h_at_zero && lam == 0.0)) {
         form_shifted_kernel<<<N, 256, 0, s>>>(W.Sinv, N, W.mblk, C.ld, C.lo, lam, W.H, nullptr);
         PPBO_LAUNCH_CHECK(ctx);
@@ -467,8 +476,9 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
         continue;
       }
       best_pd = std::fmin(best_pd, lam);
-      int split = 0;     // L^-1 is kept as two diagonal blocks + L21 (ppbo_apply_linv_async)
+      // L^-1 is kept as two diagonal blocks + L21 (ppbo_apply_linv_async)
       if (int rc = ppbo_trtri_async(ctx, W.H, N, N, W.Linv, N, s, 1, &split)) return rc;
+      }
       auto apply_linv = [&](const double* x, double* y, int trans) {
         return ppbo_apply_linv_async(ctx, W.Linv, N, W.H, N, N, split, x, y, trans, W.tmpv, s);
       };
@@ -485,6 +495,7 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
       if (!std::isfinite(pn) || !std::isfinite(gtp) || !std::isfinite(qn2))
         return ppbo_set_error(ctx, -3, "non-finite trust-region step (|p|^2=%g g.p=%g |q|^2=%g) at iteration %d", W.hsc[0],
                               gtp, qn2, it);
+      if (chord && !(pn <= radius)) { chord_abort = true; break; }   // stale factor, step too long: refactor
       have_step = true;
       lam_used = lam;
       if (verbose > 1) printf("    [inner %d]   |p| %.6e (radius %.3e)\n", inner, pn, radius);
@@ -550,6 +561,7 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
       if (lam_new == lam) break;
       lam = lam_new;
     }
+    if (chord_abort) { chord_left = 0; --it; continue; }
     lam_lb_prev = lb;
     if (!have_step) break;
     prev_lam = lam_used;
@@ -567,7 +579,7 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
     const double actual = -0.5 * T.pv + (T.Tlik - C.Tlik);
     const double rho = actual / pred;
     const double old_radius = radius;
-    if (!(rho >= 0.25)) radius *= 0.25;
+    if (!(rho >= 0.25)) { if (!chord) radius *= 0.25; }   // a poor chord step blames the stale Hessian, not the radius
     else if (rho > 0.75 && boundary) radius = std::fmin(2.0 * radius, rmax);
     shrink = radius < old_radius;
     if (verbose)
@@ -577,6 +589,9 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
       cur ^= 1;
       h_changed = true;
     }
+    // enter only in the contracting regime (the gradient fell by 5x on a full Newton step)
+    if (chord) chord_left = (rho > eta && rho >= 0.5) ? chord_left - 1 : 0;
+    else chord_left = (!boundary && lam_used == 0.0 && rho > 0.75 && std::sqrt(T.gn2) < 0.2 * gnorm) ? 2 : 0;
     if (radius < 1e-14) break;
   }
   PPBO_HIP_CHECK(ctx, hipMemcpyAsync(d_fMAP, pt[cur].f, vbytes, hipMemcpyDeviceToDevice, s));
