@@ -138,6 +138,11 @@ def main():
     post, st = fit_once()
     torch.cuda.synchronize()
     gp_fit_ms = (time.perf_counter() - t0) * 1e3
+    eng.profile(True)                # one more fit with the library's event brackets: where the fit time goes
+    fit_once()
+    torch.cuda.synchronize()
+    potrf_ms, potrf_n = eng.profile_read("potrf")
+    eng.profile(False)
     def gram_burst_ms(Xg, reps=20):
         """Average duration of back-to-back Gram launches between two events on the launch stream (a
         per-launch event bracket costs ~3 us, as much again as a third of this kernel at N = 2048)."""
@@ -261,6 +266,9 @@ def main():
                                    f"SE kernel theta={list(map(float, th))}", "N": N, "D": D, "M_per_gpu": M,
                        "parallelism": f"candidate-sharded x{world}, model replicated, 1 all-gather/step"},
             "gp_fit_ms": gp_fit_ms, "gp_fit_iterations": st["iterations"], "gp_fit_cholesky": st["n_cholesky"],
+            "gp_fit_breakdown": {"potrf_calls": potrf_n, "potrf_avg_ms": potrf_ms / max(potrf_n, 1),
+                                 "potrf_total_ms": potrf_ms,
+                                 "note": "factorizations incl. Sigma^-1 and the posterior; failed ones end early"},
             "roofline": {"bound": "mfma", "kernel": "quadform_kernel (K4: |G K*|^2)", "achieved": achieved,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
                          "traffic": None, "avg_launch_ms": qf_avg_ms, "launches": qf_n,
