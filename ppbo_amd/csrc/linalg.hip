@@ -575,25 +575,24 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
 // One workgroup: back substitution with L1^T in 64-column blocks from the bottom up; the right-hand side
 // lives in LDS, each block's triangle is staged there too, the updates above it stream rows of L.
 // out[0] = (-d) / |v|^2  (NaN when the pivot itself was not finite).
-__global__ __launch_bounds__(256) void potrf_fail_bound_kernel(const double* __restrict__ L, int ldl,
-                                                               const int* __restrict__ info,
-                                                               const double* __restrict__ fail_pivot,
-                                                               double* __restrict__ out) {
+__global__ __launch_bounds__(512) void potrf_fail_bound_kernel(const double* __restrict__ L, int ldl,
+                                                                const int* __restrict__ info,
+                                                                const double* __restrict__ fail_pivot,
+                                                                double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double flds[];
   double* Tb = flds;                 // [64][65] the current diagonal block of L
   double* vb = Tb + 64 * 65;         // [64] solved entries of the block
-  double* red = vb + 64;             // [4] wave partials
-  double* rhs = red + 4;             // [kf] right-hand side / solution
+  double* rhs = vb + 64;             // [kf] right-hand side / solution
   const int kf = *info - 1;
   const double d = *fail_pivot;
   const int t = threadIdx.x;
   if (kf < 0) { if (t == 0) out[0] = NAN; return; }
-  for (int i = t; i < kf; i += 256) rhs[i] = -L[(size_t)kf * ldl + i];
+  for (int i = t; i < kf; i += 512) rhs[i] = -L[(size_t)kf * ldl + i];
   __syncthreads();
-  double vn2 = 0.0;                  // thread-local share of |v1|^2
+  double vn2 = 0.0;                  // wave 0's share of |v1|^2
   for (int b1 = kf; b1 > 0; b1 -= 64) {
     const int b0 = (b1 >= 64) ? b1 - 64 : 0, nb = b1 - b0;
-    for (int e = t; e < nb * nb; e += 256) {
+    for (int e = t; e < nb * nb; e += 512) {
       const int r = e / nb, c = e - r * nb;
       Tb[r * 65 + c] = (c <= r) ? L[(size_t)(b0 + r) * ldl + b0 + c] : 0.0;
     }
@@ -601,27 +600,33 @@ __global__ __launch_bounds__(256) void potrf_fail_bound_kernel(const double* __r
     if (t < 64) {
       // U x = r with U = Tb^T: lane i owns r_i; columns from the last to the first
       double ri = (t < nb) ? rhs[b0 + t] : 0.0;
+      const double rv = (t < nb) ? 1.0 / Tb[t * 65 + t] : 0.0;     // one division per lane, not one per step
       for (int j = nb - 1; j >= 0; --j) {
-        const double xj = __shfl(ri, j, 64) / Tb[j * 65 + j];
+        const double xj = __shfl(ri * rv, j, 64);
         if (t == j) ri = xj;
         else if (t < j) ri -= Tb[j * 65 + t] * xj;
       }
-      if (t < nb) { vb[t] = ri; rhs[b0 + t] = ri; vn2 += ri * ri; }
+      vb[t] = (t < nb) ? ri : 0.0;
+      if (t < nb) { rhs[b0 + t] = ri; vn2 += ri * ri; }
     }
     __syncthreads();
-    // rows above the block: r_i -= sum_j L[b0+j][i] x_j
-    for (int i = t; i < b0; i += 256) {
+    // rows above the block: r_i -= sum_j L[b0+j][i] x_j.  One column per thread, all 64 rows requested at once
+    // (x_j = 0 beyond nb): the kernel is a chain of memory round trips, so each one carries as much as it can
+    for (int i = t; i < b0; i += 512) {
+      double lv[64];
+#pragma unroll
+      for (int j = 0; j < 64; ++j) lv[j] = (j < nb) ? L[(size_t)(b0 + j) * ldl + i] : 0.0;
       double acc = 0.0;
-#pragma unroll 8
-      for (int j = 0; j < nb; ++j) acc += L[(size_t)(b0 + j) * ldl + i] * vb[j];
+#pragma unroll
+      for (int j = 0; j < 64; ++j) acc += lv[j] * vb[j];
       rhs[i] -= acc;
     }
     __syncthreads();
   }
-  vn2 = wave_sum(vn2);
-  if ((t & 63) == 0) red[t >> 6] = vn2;
-  __syncthreads();
-  if (t == 0) out[0] = (-d) / (1.0 + ((red[0] + red[1]) + (red[2] + red[3])));
+  if (t < 64) {
+    vn2 = wave_sum(vn2);
+    if (t == 0) out[0] = (-d) / (1.0 + vn2);
+  }
 }
 
 // diagonal factors parked by potrf_step_kernel -> lower triangles of A's diagonal blocks
@@ -869,14 +874,14 @@ int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hi
 
 int ppbo_potrf_fail_bound_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, const int* d_info,
                                 const double* d_fail_pivot, double* d_out, hipStream_t s) {
-  const size_t lds = ((size_t)64 * 65 + 64 + 4 + N) * sizeof(double);
+  const size_t lds = ((size_t)64 * 65 + 64 + N) * sizeof(double);
   if (lds > 150 * 1024) return 1;     // leading block too large for the LDS-resident right-hand side: no bound
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)potrf_fail_bound_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_done = true;
   }
-  potrf_fail_bound_kernel<<<1, 256, lds, s>>>(d_L, ldl, d_info, d_fail_pivot, d_out);
+  potrf_fail_bound_kernel<<<1, 512, lds, s>>>(d_L, ldl, d_info, d_fail_pivot, d_out);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
