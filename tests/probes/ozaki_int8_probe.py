@@ -1,5 +1,5 @@
 import sys, numpy as np, scipy.linalg
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from oracle import ppbo_oracle as orc
 def slices(M, S, axis):
     # per-row (axis=1) or per-column (axis=0) scaling; 7-bit signed slices
