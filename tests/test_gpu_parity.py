@@ -52,7 +52,7 @@ def test_dgemm_mfma_layout_is_not_transposed(eng):
     assert np.array_equal(out, B)
 
 
-@pytest.mark.parametrize("N", [1, 17, 63, 64, 65, 100, 129, 200, 512, 650, 1031, 2500])
+@pytest.mark.parametrize("N", [1, 17, 63, 64, 65, 100, 129, 200, 512, 650, 1031, 2500, 4200])
 def test_potrf_and_inverse(eng, N):
     rng = np.random.default_rng(N)
     Q = rng.standard_normal((N, N))
