@@ -8,8 +8,9 @@
 //   var(x) = sigma_f^2 - k*' A k*,  A = Sigma^-1 - Sigma^-1 P Sigma^-1  (gp_model.py:449)
 //          = sigma_f^2 + k*' Lambda k* + |G k*|^2                        (Woodbury, same operator)
 // Pass 1 (kstar_kernel, VALU): one lane = two candidates held in registers, X rows staged in LDS
-//   and read as broadcasts (direct differences: alpha has cond(Sigma)-size entries, so K* keeps full
-//   fp64 accuracy); writes K*[N, Mc] (j-major) once and reduces mu and k*'Lambda k* in registers.
+//   and read as broadcasts (SE / RQ: the reference's expansion with the candidate pre-scaled by -2, one FMA
+//   per dimension; camphor: differences); writes K*[N, Mc] (j-major) once and reduces mu and k*'Lambda k*
+//   in registers.
 // Pass 2 (quadform_kernel, fp64 MFMA): Y = G K* on 128x128 tiles (8 wavefronts of 32x64), K range cut
 //   at the block-triangular edge per wavefront, epilogue = column sums of Y^2 into per-row-tile slabs.
 //   Workgroups are ordered candidate-tile-fastest in chunks of 64 tiles (PPBO_QF_ORDER, default 258):
@@ -25,13 +26,15 @@ namespace {
 using namespace gemm64;
 
 constexpr int KS_THREADS = 256;
-constexpr int KS_CPT = 2;  // candidates per thread
+constexpr int KS_CPT = 2;  // candidates per thread (even); 4 halves the LDS reads per pair but was measured slower (fewer waves, 32-byte store pieces)
 
 constexpr int KS_RJ = 32;   // X rows staged in LDS per step
 
 // DP = padded dimension (compile time): X rows are zero-padded to DP in LDS and the
 // candidate registers likewise, so the inner product loop is branch-free and fully
 // unrolled; every lane reads the same LDS address (broadcast), one ds_read_b128 per 2 dims.
+// KS_CPT candidates per lane share each of those reads: with the one-FMA-per-dimension form the kernel is
+// bound by the LDS pipe (a broadcast b128 read still returns 1 KB per wavefront), not by the vector ALUs.
 template <int KID, int DP>
 __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
     const double* __restrict__ X, int N, int D, KernParams p, const double* __restrict__ alpha,
@@ -39,19 +42,29 @@ __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
     const double* __restrict__ Xc, int M, double* __restrict__ Kt, int ldk, double* __restrict__ mu_part,
     double* __restrict__ t_part, int q_per_split, int n_q) {
   __shared__ __attribute__((aligned(16))) double xs[KS_RJ * DP];
-  __shared__ double s_alpha[KS_RJ], s_ld[KS_RJ], s_lo[KS_RJ];
+  __shared__ double s_alpha[KS_RJ], s_ld[KS_RJ], s_lo[KS_RJ], s_nx[KS_RJ];
   const int c0 = (blockIdx.x * KS_THREADS + threadIdx.x) * KS_CPT;
-  double xa[DP], xb[DP];
+  // SE / RQ use the reference's own expansion r^2 = (|x|^2 + |c|^2) - 2 x.c (kernels.py:7-10) with the
+  // candidate pre-scaled by -2: one FMA per dimension and pair instead of a subtract and an FMA.  Its
+  // rounding is the rounding every entry of Sigma already carries (posterior mean / variance move by
+  // <= 3e-13 / 1e-13 sigma_f^2 on the fixtures against direct differences).  The camphor kernel needs the
+  // differences themselves.
+  constexpr bool EXPAND = (KID != PPBO_KERNEL_CAMPHOR);
+  double xc[KS_CPT][DP], nc[KS_CPT], mu[KS_CPT], tl[KS_CPT], ko[KS_CPT];
 #pragma unroll
-  for (int d = 0; d < DP; ++d) {
-    xa[d] = (d < D && c0 < M) ? Xc[(size_t)c0 * D + d] : 0.0;
-    xb[d] = (d < D && c0 + 1 < M) ? Xc[(size_t)(c0 + 1) * D + d] : 0.0;
+  for (int q = 0; q < KS_CPT; ++q) {
+    nc[q] = 0.0; mu[q] = 0.0; tl[q] = 0.0; ko[q] = 0.0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      double v = (d < D && c0 + q < M) ? Xc[(size_t)(c0 + q) * D + d] : 0.0;
+      if (EXPAND) { nc[q] = fma(v, v, nc[q]); v *= -2.0; }
+      xc[q][d] = v;
+    }
   }
   const int j_beg = blockIdx.y * q_per_split * mblk;
   int j_end = j_beg + q_per_split * mblk;
   if (j_end > N) j_end = N;
-  double mu0 = 0.0, mu1 = 0.0, t0 = 0.0, t1 = 0.0, ko0 = 0.0, ko1 = 0.0;
-  const bool vec = (Kt != nullptr) && ((ldk & 1) == 0) && (c0 + 1 < M);
+  const bool vec = (Kt != nullptr) && ((ldk & 1) == 0) && (c0 + KS_CPT - 1 < M);
   const bool has_lam = (lam_diag != nullptr);
   int rb = 0;  // row index inside the current star block (splits start on a block edge)
   for (int row0 = j_beg; row0 < j_end; row0 += KS_RJ) {
@@ -67,52 +80,75 @@ __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
       s_alpha[threadIdx.x] = ok ? alpha[j] : 0.0;
       s_ld[threadIdx.x] = (ok && has_lam) ? lam_diag[j] : 0.0;
       s_lo[threadIdx.x] = (ok && has_lam) ? lam_off[j] : 0.0;
+      if (EXPAND) {
+        double nx = 0.0;
+        if (ok)
+          for (int d = 0; d < D; ++d) { const double v = X[(size_t)j * D + d]; nx = fma(v, v, nx); }
+        s_nx[threadIdx.x] = nx;
+      }
     }
     __syncthreads();
     const int rmax = (j_end - row0 < KS_RJ) ? (j_end - row0) : KS_RJ;
     for (int r = 0; r < rmax; ++r) {
       const double* __restrict__ xr = xs + r * DP;
-      double s0 = 0.0, s1 = 0.0;
+      double sv[KS_CPT];
 #pragma unroll
-      for (int d = 0; d < DP; ++d) {
-        const double x = xr[d];
-        s0 += kern_term<KID>(x - xa[d], d, p);
-        s1 += kern_term<KID>(x - xb[d], d, p);
+      for (int q = 0; q < KS_CPT; ++q) sv[q] = 0.0;
+      if (EXPAND) {
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+          const double x = xr[d];
+#pragma unroll
+          for (int q = 0; q < KS_CPT; ++q) sv[q] = fma(x, xc[q][d], sv[q]);
+        }
+        const double nx = s_nx[r];
+#pragma unroll
+        for (int q = 0; q < KS_CPT; ++q) sv[q] = fmax(sv[q] + (nx + nc[q]), 0.0);
+      } else {
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+          const double x = xr[d];
+#pragma unroll
+          for (int q = 0; q < KS_CPT; ++q) sv[q] += kern_term<KID>(x - xc[q][d], d, p);
+        }
       }
-      const double k0 = kern_finish<KID>(s0, p), k1 = kern_finish<KID>(s1, p);
+      double kv[KS_CPT];
+#pragma unroll
+      for (int q = 0; q < KS_CPT; ++q) kv[q] = kern_finish<KID>(sv[q], p);
       if (Kt) {
         double* dst = Kt + (size_t)(row0 + r) * ldk + c0;
-        if (vec) store_through2(dst, k0, k1);      // 1 GB streamed out once, read back by the next kernel
-        else {
-          if (c0 < M) dst[0] = k0;
-          if (c0 + 1 < M) dst[1] = k1;
+        if (vec) {      // 1 GB streamed out once, read back by the next kernel
+#pragma unroll
+          for (int q = 0; q < KS_CPT; q += 2) store_through2(dst + q, kv[q], kv[q + 1]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < KS_CPT; ++q)
+            if (c0 + q < M) dst[q] = kv[q];
         }
       }
       const double a = s_alpha[r];
-      mu0 += a * k0;
-      mu1 += a * k1;
+#pragma unroll
+      for (int q = 0; q < KS_CPT; ++q) mu[q] += a * kv[q];
       if (has_lam) {
         const double ld = s_ld[r];
         if (rb == 0) {
-          ko0 = k0; ko1 = k1;
-          t0 += ld * k0 * k0;
-          t1 += ld * k1 * k1;
+#pragma unroll
+          for (int q = 0; q < KS_CPT; ++q) { ko[q] = kv[q]; tl[q] += ld * kv[q] * kv[q]; }
         } else {
           const double lo2 = 2.0 * s_lo[r];
-          t0 += k0 * (ld * k0 + lo2 * ko0);
-          t1 += k1 * (ld * k1 + lo2 * ko1);
+#pragma unroll
+          for (int q = 0; q < KS_CPT; ++q) tl[q] += kv[q] * (ld * kv[q] + lo2 * ko[q]);
         }
       }
       if (++rb == mblk) rb = 0;
     }
   }
-  if (c0 < M) {
-    mu_part[(size_t)blockIdx.y * M + c0] = mu0;
-    if (t_part) t_part[(size_t)blockIdx.y * M + c0] = t0;
-  }
-  if (c0 + 1 < M) {
-    mu_part[(size_t)blockIdx.y * M + c0 + 1] = mu1;
-    if (t_part) t_part[(size_t)blockIdx.y * M + c0 + 1] = t1;
+#pragma unroll
+  for (int q = 0; q < KS_CPT; ++q) {
+    if (c0 + q < M) {
+      mu_part[(size_t)blockIdx.y * M + c0 + q] = mu[q];
+      if (t_part) t_part[(size_t)blockIdx.y * M + c0 + q] = tl[q];
+    }
   }
 }
 
