@@ -288,12 +288,12 @@ def main():
             "secondary": secondary,
             "best": {"value": best[0], "index": best[1]},
         }
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hot_kernels_v5.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hot_kernels_v6.json")
         if os.path.exists(pmc):   # fabric-side bytes per launch from the committed rocprofv3 --pmc passes (same command)
             try:
                 d = json.load(open(pmc))["quadform"]["derived"]
                 line["roofline"]["traffic"] = d["fabric_read_bytes(FETCH_SIZE KB x1024 x2 gfx950 correction)"] + d["write_bytes"]
-                line["roofline"]["traffic_source"] = "profiles/r01_pmc_hot_kernels_v5.json (FETCH_SIZE x2 + WRITE_SIZE)"
+                line["roofline"]["traffic_source"] = "profiles/r01_pmc_hot_kernels_v6.json (FETCH_SIZE x2 + WRITE_SIZE)"
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
