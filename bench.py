@@ -4,11 +4,15 @@
 One "step" = one pass of the candidate-scoring hot path over one batch of M synthetic
 candidates already resident in HBM: K* build + posterior mean (K2+K3), posterior variance
 through the fp64-MFMA quadratic form (K4), pointwise-EI score and the on-device argmax,
-plus (N>1) one RCCL all-gather of the 16-byte (score, index) record.  Weak scaling: every
-rank scores its own M candidates against the same replicated model.
+plus (N>1) one RCCL all-gather of the 16-byte (score, index) record.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py                                   # C3, 1 GPU
+    python bench.py --gpus 8                          # spawns 8 ranks itself (torch.distributed.run)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # the driver's form
+    python bench.py --gpus 8 --config c4              # BASELINE config 4: 262144 candidates SHARDED over the ranks
+
+--scaling weak (default except c4): every rank scores its own --candidates rows against the same replicated
+model.  --scaling strong (default for c4): --candidates is the job total, rank r scores rows shard_bounds(M, r, N).
 """
 from __future__ import annotations
 
@@ -90,25 +94,66 @@ def cpu_baseline(g, M_sample, seconds_budget=25.0, gpu_check=None):
                 parity_vs_oracle=parity)
 
 
+# BASELINE.json configs that have a committed design fixture: name, default candidate count, default scaling
+WORKLOADS = {
+    "c2": ("C2 Hartmann6-shaped", 16384, "weak"),
+    "c3": ("C3 Ackley-shaped", 65536, "weak"),
+    "c4": ("C4 Levy-shaped", 262144, "strong"),
+    "c5": ("C5 camphor/Cu(111)-shaped", 65536, "weak"),
+}
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` outside torchrun: start N rank processes (one per GPU, RCCL) as a CHILD job and
+    relay its output.  Nothing in this parent has touched HIP (torch is not even imported), so no process that
+    initialised a GPU is ever replaced or forked."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c3", help="golden design to fit (c3 = Ackley-shaped N=2048, D=20)")
-    ap.add_argument("--candidates", type=int, default=65536)
+    ap.add_argument("--config", default="c3", choices=sorted(WORKLOADS),
+                    help="design fixture to fit (c3 = Ackley-shaped N=2048, D=20: the configuration the metric is quoted on)")
+    ap.add_argument("--candidates", type=int, default=0, help="0 = the config's own M (c3: 65536, c4: 262144 ...)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="weak: --candidates per rank; strong: --candidates in total, sharded (default: per config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the RFF / line-acquisition side measurements")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from ppbo_amd.engine import Engine, SCORE_POINTWISE_EI
-    from ppbo_amd.dist import allgather_argmax
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                 f"(or run `python bench.py --gpus {args.gpus}` without torchrun and let it spawn the ranks)")
+    wl_name, m_default, scaling_default = WORKLOADS[args.config]
+    scaling = args.scaling or scaling_default
+    M_arg = args.candidates or m_default
+
+    import torch
+    import torch.distributed as dist
+    from ppbo_amd.engine import Engine, SCORE_POINTWISE_EI
+    from ppbo_amd.dist import allgather_argmax, shard_bounds
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no ROCm GPU visible (torch.cuda.is_available() is False); the product has no CPU path")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -121,7 +166,13 @@ def main():
     g = synth_model_inputs(args.config)
     X, th, m, kern = g["X"], g["theta"], int(g["m"]), str(g["kernel"])
     N, D = X.shape
-    M = args.candidates
+    if scaling == "strong":      # the job scores M_arg candidates in total; this rank owns a contiguous row block
+        row_lo, row_hi = shard_bounds(M_arg, rank, world)
+        M_total = M_arg
+    else:                        # every rank scores M_arg candidates of its own
+        row_lo, row_hi = rank * M_arg, (rank + 1) * M_arg
+        M_total = M_arg * world
+    M = row_hi - row_lo
 
     # ---- GP fit (untimed for the step metric, reported as gp_fit_ms) -------------------
     Xd = eng.dev(X)
@@ -166,7 +217,7 @@ def main():
     def step():
         out = eng.predict(post, Xc, score=SCORE_POINTWISE_EI, mustar=mustar, want_mu=False, want_var=False,
                           want_score=False, want_best=True)
-        gidx = out["best_idx"] + rank * M
+        gidx = out["best_idx"] + row_lo
         return allgather_argmax(out["best_val"], gidx, device=dev)
 
     for _ in range(args.warmup):
@@ -207,7 +258,17 @@ def main():
         om = eng.dev(np.random.default_rng(5).standard_normal(F))
         eng.profile_reset()
         t_proj = timed(lambda: eng.rff_project(Xd, W, b, th[2]), 10)
-        pj_ms, pj_n = eng.profile_read("rff_project")
+        Phi_out = eng.empty(F, N)
+        for _ in range(3):
+            eng.rff_project(Xd, W, b, th[2], out=Phi_out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):                     # back-to-back launches between two events: the sustained rate
+            eng.rff_project(Xd, W, b, th[2], out=Phi_out)
+        e1.record()
+        e1.synchronize()
+        pj_burst_ms = e0.elapsed_time(e1) / 20
+        del Phi_out
         t_rs = timed(lambda: eng.rff_score(Xc, W, b, th[2], om, want_score=False), 5)
         rs_ms, rs_n = eng.profile_read("rff_score")
         B, G, S = 512, 70, 150
@@ -235,45 +296,51 @@ def main():
             del Xg
         secondary = {
             "gram_kernel_larger_N": gram_sizes,
-            "rff_project": {"F": F, "wall_ms_per_call": t_proj * 1e3, "event_ms": pj_ms / max(pj_n, 1), "bytes": phi_bytes,
-                            "note": "rocprofv3 kernel time is in profiles/ (28.5 us = 2.35 TB/s); the event bracket "
-                                    "includes launch latency for this kernel"},
+            "rff_project": {"F": F, "wall_ms_per_call": t_proj * 1e3, "avg_ms": pj_burst_ms, "bytes": phi_bytes,
+                            "bound": "hbm", "achieved_GBs": phi_bytes / (pj_burst_ms * 1e-3) / 1e9,
+                            "frac": phi_bytes / (pj_burst_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                            "note": "avg_ms = back-to-back launches between two events (sustained); wall = one call incl. "
+                                    "allocation and launch latency"},
             "rff_score_evals_per_s": M / t_rs, "rff_score_kernel_ms": rs_ms / max(rs_n, 1),
             "line_acq": {"lines": B, "grid": G, "draws": S, "ms": t_line * 1e3, "lines_per_s": B / t_line},
         }
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * M * args.steps / elapsed
+        value = M_total * args.steps / elapsed
         qf_avg_ms = qf_ms / max(qf_n, 1)
         mblk = m + 1
         # algorithmic flops of the variance contraction per launch: 2 M N^2 (dense A);
         # executed: the block-triangular G form does M * sum_tiles 2*128*kend(tile) flops
         algo_flops = 2.0 * M * N * N
         # executed: each wavefront owns 32 rows of a 128-row tile and stops at the end of their last star block
+        # (equals SQ_INSTS_MFMA x 2048 of the rocprofv3 --pmc pass, profiles/)
         wrows = 32
         exec_flops = sum(2.0 * wrows * M * min(N, -(-((b + 1) * wrows) // mblk) * mblk) for b in range(-(-N // wrows)))
-        achieved = algo_flops / (qf_avg_ms * 1e-3) / 1e12
+        dense_equiv = algo_flops / (qf_avg_ms * 1e-3) / 1e12
         executed = exec_flops / (qf_avg_ms * 1e-3) / 1e12
         gram_bytes = 8.0 * N * N + 8.0 * N * D
         gram_avg_ms = gram_ms / max(gram_n, 1)
         line = {
             "metric": "acquisition evals/sec (posterior mean + variance + EI + argmax per candidate)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C3 Ackley-shaped: N={N} obs rows (m=31), D={D}, M={M} candidates/GPU, "
-                                   f"SE kernel theta={list(map(float, th))}", "N": N, "D": D, "M_per_gpu": M,
-                       "parallelism": f"candidate-sharded x{world}, model replicated, 1 all-gather/step"},
+            "config": {"workload": f"{wl_name}: N={N} obs rows (m={m}), D={D}, M={M_total} candidates in total "
+                                   f"({M} on rank 0), {kern} theta={list(map(float, th))}", "name": args.config,
+                       "N": N, "D": D, "M_total": M_total, "M_per_gpu": M,
+                       "parallelism": f"candidates sharded x{world} ({scaling}), model replicated, 1 all-gather/step"},
             "gp_fit_ms": gp_fit_ms, "gp_fit_iterations": st["iterations"], "gp_fit_cholesky": st["n_cholesky"],
             "gp_fit_breakdown": {"potrf_calls": potrf_n, "potrf_avg_ms": potrf_ms / max(potrf_n, 1),
                                  "potrf_total_ms": potrf_ms,
                                  "note": "factorizations incl. Sigma^-1 and the posterior; failed ones end early"},
-            "roofline": {"bound": "mfma", "kernel": "quadform_kernel (K4: |G K*|^2)", "achieved": achieved,
-                         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+            # achieved / frac = MFMA flops the kernel EXECUTES (block-triangular G) over the live event
+            # time: never above 1.  The dense-A figure SURVEY 8(d) prices (2 M N^2) is the side key.
+            "roofline": {"bound": "mfma", "kernel": "quadform_kernel (K4: |G K*|^2)", "achieved": executed,
+                         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": executed / PEAK_FP64_MFMA_TFLOPS,
                          "traffic": None, "avg_launch_ms": qf_avg_ms, "launches": qf_n,
-                         "algorithmic_flops_per_launch": algo_flops, "executed_flops_per_launch": exec_flops,
-                         "executed_tflops": executed, "executed_frac": executed / PEAK_FP64_MFMA_TFLOPS},
+                         "executed_flops_per_launch": exec_flops,
+                         "dense_equivalent_flops_per_launch": algo_flops, "dense_equivalent_tflops": dense_equiv},
             "kernels": {
                 "kstar_kernel": {"avg_ms": ks_ms / max(ks_n, 1), "launches": ks_n},
                 "score_kernel": {"avg_ms": sc_ms / max(sc_n, 1), "launches": sc_n},
@@ -288,15 +355,22 @@ def main():
             "secondary": secondary,
             "best": {"value": best[0], "index": best[1]},
         }
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hot_kernels_v6.json")
-        if os.path.exists(pmc):   # fabric-side bytes per launch from the committed rocprofv3 --pmc passes (same command)
+        # `traffic` needs rocprofv3 --pmc passes and cannot be measured from inside this process: it stays null.
+        # The last committed PMC capture is quoted beside it ONLY while the kernel sources are the ones it was
+        # taken with (tools/pmc_quadform.sh records the csrc digest).
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_hot_kernels.json")
+        if os.path.exists(pmc):
             try:
-                d = json.load(open(pmc))["quadform"]["derived"]
-                line["roofline"]["traffic"] = d["fabric_read_bytes(FETCH_SIZE KB x1024 x2 gfx950 correction)"] + d["write_bytes"]
-                line["roofline"]["traffic_source"] = "profiles/r01_pmc_hot_kernels_v6.json (FETCH_SIZE x2 + WRITE_SIZE)"
+                from ppbo_amd.build import _digest
+                doc = json.load(open(pmc))
+                d = doc["quadform"]["derived"]
+                line["roofline"]["traffic_from_profile"] = {
+                    "bytes_per_launch": d["fabric_read_bytes(FETCH_SIZE KB x1024 x2 gfx950 correction)"] + d["write_bytes"],
+                    "source": "profiles/r02_pmc_hot_kernels.json (FETCH_SIZE x2 + WRITE_SIZE, C3 launch)",
+                    "csrc_digest": doc.get("csrc_digest"), "current": doc.get("csrc_digest") == _digest()}
             except Exception:
                 pass
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config in ("c2", "c3"):   # sigma = 0.001 oracle fits (c4, c5) take minutes to hours
             # the oracle uses the reference's fMAP from the fixture; score the same subsample with that model
             Sinv_d = eng.pd_inverse(eng.gram(Xd, th, kern))
             post_ref = eng.posterior(Xd, th, kern, Sinv_d, g["fMAP"], m)

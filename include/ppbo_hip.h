@@ -15,7 +15,10 @@
  *     C-contiguous float64 unless stated); h_* are HOST pointers.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *     Functions with host outputs synchronise that stream before returning.
- *   - one ppbo_ctx per process/device; a ctx owns only private workspaces.
+ *   - a ppbo_ctx is bound to ONE device; every entry point runs on that device and restores
+ *     the caller's current device on return.  Several contexts (on the same or different
+ *     devices) may live in one process; a single ctx is not re-entrant across threads.
+ *     A ctx owns only private workspaces; the library has no process-global mutable state.
  */
 #ifndef PPBO_HIP_H
 #define PPBO_HIP_H
@@ -27,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PPBO_ABI_VERSION 1
+#define PPBO_ABI_VERSION 2
 #define PPBO_ERR_NOT_PD 1001
 
 typedef struct ppbo_ctx ppbo_ctx;

@@ -69,6 +69,20 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2     # must equal PPBO_ABI_VERSION of include/ppbo_hip.h
+
+
+def _check_stamp():
+    """The .so is git-ignored: make sure it was built from the csrc/ + header that are on disk now."""
+    from . import build as _build
+    if os.environ.get("PPBO_SKIP_STAMP_CHECK"):
+        return
+    if not os.path.exists(_build.STAMP):
+        raise ImportError(f"{_build.STAMP} is missing: {LIB_PATH} is of unknown provenance; rebuild it with "
+                          "`python -m ppbo_amd.build --force`")
+    if open(_build.STAMP).read().strip() != _build._digest():
+        raise ImportError(f"{LIB_PATH} is stale (csrc/ or include/ppbo_hip.h changed since it was built): "
+                          "rebuild it with `python -m ppbo_amd.build`")
 
 
 def load():
@@ -80,7 +94,12 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m ppbo_amd.build` (hipcc, gfx950). "
             "ppbo_amd has no CPU fallback.")
+    _check_stamp()
     lib = C.CDLL(LIB_PATH)
+    lib.ppbo_abi_version.restype = C.c_int
+    if lib.ppbo_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} reports ABI {lib.ppbo_abi_version()}, this binding expects {ABI_VERSION}: "
+                          "rebuild it with `python -m ppbo_amd.build --force`")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name, None)
         if fn is None:

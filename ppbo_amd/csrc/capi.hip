@@ -45,6 +45,19 @@ void* ppbo_pinned(ppbo_ctx* ctx, size_t bytes) {
   return p;
 }
 
+void ppbo_lds_limit(ppbo_ctx* ctx, const void* kernel_fn, int bytes) {
+  for (const void* f : ctx->lds_raised)
+    if (f == kernel_fn) return;
+  // the largest size any caller asks for is fixed per kernel, so one call per kernel and device suffices
+  (void)hipFuncSetAttribute(kernel_fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  ctx->lds_raised.push_back(kernel_fn);
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 extern "C" {
 
 int ppbo_abi_version(void) { return PPBO_ABI_VERSION; }
@@ -56,24 +69,33 @@ int ppbo_ctx_create(int device, ppbo_ctx** out) {
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) return (int)e;
   if (device < 0 || device >= n) return -1;
-  e = hipSetDevice(device);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  e = hipSetDevice(device);           // validates the device; the caller's current device is restored below
   if (e != hipSuccess) return (int)e;
+  if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
   ppbo_ctx* c = new (std::nothrow) ppbo_ctx();
   if (!c) return -2;
   c->device = device;
+  c->qf_variant = env_int("PPBO_QF_VARIANT", 2);
+  if (c->qf_variant < 0 || c->qf_variant > 5) c->qf_variant = 0;
+  c->qf_order = env_int("PPBO_QF_ORDER", 258);
+  c->potrf_gen = env_int("PPBO_POTRF_GEN", 3);
   *out = c;
   return 0;
 }
 
 int ppbo_ctx_destroy(ppbo_ctx* ctx) {
   if (!ctx) return 0;
-  (void)hipSetDevice(ctx->device);
+  {
+  PpboDeviceGuard guard(ctx);
   (void)hipDeviceSynchronize();
   for (int i = 0; i < ppbo_ctx::WS_COUNT; ++i)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (int i = 0; i < ppbo_ctx::PF_COUNT; ++i)
     for (auto& pr : ctx->pf_events[i]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  }
   delete ctx;
   return 0;
 }
@@ -99,6 +121,7 @@ int ppbo_profile_reset(ppbo_ctx* ctx) {
 
 int ppbo_profile_read(ppbo_ctx* ctx, const char* name, double* h_total_ms, int* h_count) {
   if (!ctx || !name) return -1;
+  PpboDeviceGuard guard(ctx);
   const int slot = pf_slot(name);
   if (slot < 0) return ppbo_set_error(ctx, -1, "unknown profile name %s", name);
   double tot = 0.0;

@@ -29,7 +29,26 @@ struct ppbo_ctx {
   enum { PF_GRAM = 0, PF_KSTAR, PF_QUADFORM, PF_SCORE, PF_RFF_PROJECT, PF_RFF_SCORE, PF_POTRF, PF_COUNT };
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pf_events[PF_COUNT];
   size_t pf_used[PF_COUNT] = {};
+  // kernels whose dynamic-LDS limit has been raised on THIS ctx's device (hipFuncSetAttribute is per device)
+  std::vector<const void*> lds_raised;
+  // tuning knobs, read from the environment once per ctx (ppbo_ctx_create); defaults = measured best
+  int qf_variant = 2, qf_order = 258, potrf_gen = 3;
 };
+
+// Every extern "C" entry runs on its ctx's device and leaves the caller's current device as it found it.
+struct PpboDeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit PpboDeviceGuard(const ppbo_ctx* c) {
+    if (c && hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = (hipSetDevice(c->device) == hipSuccess);
+  }
+  ~PpboDeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+  PpboDeviceGuard(const PpboDeviceGuard&) = delete;
+  PpboDeviceGuard& operator=(const PpboDeviceGuard&) = delete;
+};
+#define PPBO_ENTER(ctx)      \
+  if (!(ctx)) return -1;     \
+  PpboDeviceGuard _ppbo_dev_guard(ctx)
 
 // RAII bracket: records two events around a launch when profiling is on
 struct PpboProfScope {
@@ -53,6 +72,8 @@ int ppbo_set_error(ppbo_ctx* ctx, int code, const char* fmt, ...);
 // returns a device pointer of at least `bytes` (contents undefined); nullptr on failure
 void* ppbo_workspace(ppbo_ctx* ctx, int slot, size_t bytes);
 void* ppbo_pinned(ppbo_ctx* ctx, size_t bytes);
+// raise a kernel's dynamic-LDS limit to `bytes` once per ctx (i.e. once per device)
+void ppbo_lds_limit(ppbo_ctx* ctx, const void* kernel_fn, int bytes);
 
 #define PPBO_HIP_CHECK(ctx, expr)                                                      \
   do {                                                                                 \

@@ -320,7 +320,7 @@ extern "C" {
 
 int ppbo_laplace_terms(ppbo_ctx* ctx, const double* d_f, int N, int m, double sigma, double* d_Tlik,
                        double* d_beta, double* d_lam_diag, double* d_lam_off, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_f && N > 0 && m >= 1 && sigma > 0, "arguments");
   PPBO_REQUIRE(ctx, N % (m + 1) == 0, "N must be n_q*(m+1) (feedback_processing.py:110-130)");
   hipStream_t s = (hipStream_t)stream;
@@ -338,7 +338,7 @@ int ppbo_laplace_terms(ppbo_ctx* ctx, const double* d_f, int N, int m, double si
 
 int ppbo_T_and_grad(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_f, int N, int m, double sigma,
                     double* h_T, double* d_grad, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_Sigma_inv && d_f && N > 0 && m >= 1 && sigma > 0, "arguments");
   PPBO_REQUIRE(ctx, N % (m + 1) == 0, "N must be n_q*(m+1)");
   hipStream_t s = (hipStream_t)stream;
@@ -364,7 +364,7 @@ int ppbo_T_and_grad(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_f,
 
 int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double sigma, const double* d_f_init,
                   const ppbo_fit_opts* opts, double* d_fMAP, ppbo_fit_stats* h_stats, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_Sigma_inv && d_f_init && d_fMAP, "null pointer");
   PPBO_REQUIRE(ctx, N > 0 && m >= 1 && sigma > 0, "sizes");
   PPBO_REQUIRE(ctx, N % (m + 1) == 0, "N must be n_q*(m+1)");
@@ -609,7 +609,7 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
 int ppbo_posterior(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fMAP, int N, int m, double sigma,
                    double* d_alpha, double* d_lam_diag, double* d_lam_off, double* d_G, double* d_P, int* h_info,
                    void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_Sigma_inv && d_fMAP && d_alpha && d_lam_diag && d_lam_off && d_G, "null pointer");
   PPBO_REQUIRE(ctx, N > 0 && m >= 1 && sigma > 0 && N % (m + 1) == 0, "sizes");
   hipStream_t s = (hipStream_t)stream;

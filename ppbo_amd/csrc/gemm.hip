@@ -80,13 +80,11 @@ template <class GC>
 int launch_cfg(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, hipStream_t s) {
   const int ntm = (g.M + GC::BM - 1) / GC::BM, ntn = (g.N + GC::BN - 1) / GC::BN;
   const size_t lds = GC::LDS_DOUBLES * sizeof(double);
-  static bool attr_done = false;
-  if (!attr_done && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)dgemm_kernel<GC, KC, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dgemm_kernel<GC, KC, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dgemm_kernel<GC, RC, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dgemm_kernel<GC, RC, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  if (lds > 64 * 1024) {
+    ppbo_lds_limit(ctx, (const void*)dgemm_kernel<GC, KC, RC>, (int)lds);
+    ppbo_lds_limit(ctx, (const void*)dgemm_kernel<GC, KC, KC>, (int)lds);
+    ppbo_lds_limit(ctx, (const void*)dgemm_kernel<GC, RC, RC>, (int)lds);
+    ppbo_lds_limit(ctx, (const void*)dgemm_kernel<GC, RC, KC>, (int)lds);
   }
   const dim3 grid(ntm * ntn, g.batch > 1 ? g.batch : 1);
   if (!transA && !transB) dgemm_kernel<GC, KC, RC><<<grid, GC::NT, lds, s>>>(g);
@@ -114,7 +112,7 @@ int ppbo_gemm_launch(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, h
 extern "C" int ppbo_dgemm(ppbo_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha,
                           const double* d_A, int lda, const double* d_B, int ldb, double beta, double* d_C,
                           int ldc, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_A && d_B && d_C, "null pointer");
   PPBO_REQUIRE(ctx, M >= 0 && N >= 0 && K >= 0, "sizes");
   GemmArgs g{};

@@ -307,7 +307,7 @@ extern "C" {
 
 int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, const double h_theta[3],
               double shrink, double* d_Sigma, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_X && d_Sigma && h_theta, "null pointer");
   PPBO_REQUIRE(ctx, N > 0 && D > 0 && D <= 64, "N>0, 0<D<=64");
   PPBO_REQUIRE(ctx, kernel_id >= 0 && kernel_id <= 2, "kernel_id");
@@ -316,14 +316,7 @@ int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, con
   const int nt = (N + TS - 1) / TS;
   const int nblk = nt * (nt + 1) / 2;
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_done = false;
-  if (!attr_done) {   // D up to 64 needs more than the default 64 KB of dynamic LDS
-    const int cap = 112 * 1024;
-    (void)hipFuncSetAttribute((const void*)gram_kernel<PPBO_KERNEL_CAMPHOR>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void*)crosscov_kernel<PPBO_KERNEL_SE>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    (void)hipFuncSetAttribute((const void*)crosscov_kernel<PPBO_KERNEL_RQ>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    attr_done = true;
-  }
+  ppbo_lds_limit(ctx, (const void*)gram_kernel<PPBO_KERNEL_CAMPHOR>, 112 * 1024);
   PpboProfScope pf(ctx, ppbo_ctx::PF_GRAM, s);
   if (kernel_id != PPBO_KERNEL_CAMPHOR) {
 #define GM_LAUNCH(DPV)                                                                                       \
@@ -332,12 +325,10 @@ int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, con
     constexpr int body = 2 * TS * LDv + 2 * TS + 8 * 16 * 18;                                                \
     const size_t lds = (size_t)body * sizeof(double);                                                        \
     if (kernel_id == PPBO_KERNEL_SE) {                                                                       \
-      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gram_mfma_kernel<PPBO_KERNEL_SE, DPV>,     \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      if (lds > 64 * 1024) ppbo_lds_limit(ctx, (const void*)gram_mfma_kernel<PPBO_KERNEL_SE, DPV>, (int)lds); \
       gram_mfma_kernel<PPBO_KERNEL_SE, DPV><<<nblk, 512, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);       \
     } else {                                                                                                 \
-      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gram_mfma_kernel<PPBO_KERNEL_RQ, DPV>,     \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      if (lds > 64 * 1024) ppbo_lds_limit(ctx, (const void*)gram_mfma_kernel<PPBO_KERNEL_RQ, DPV>, (int)lds); \
       gram_mfma_kernel<PPBO_KERNEL_RQ, DPV><<<nblk, 512, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);       \
     }                                                                                                        \
   } while (0)
@@ -361,7 +352,7 @@ int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, con
 
 int ppbo_cross_cov(ppbo_ctx* ctx, int kernel_id, const double* d_X1, int n1, const double* d_X2, int n2,
                    int D, const double h_theta[3], double* d_K, int ldk, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_X1 && d_X2 && d_K && h_theta, "null pointer");
   PPBO_REQUIRE(ctx, n1 > 0 && n2 > 0 && D > 0 && D <= 64 && ldk >= n2, "sizes (D<=64)");
   PPBO_REQUIRE(ctx, kernel_id >= 0 && kernel_id <= 2, "kernel_id");
@@ -370,6 +361,10 @@ int ppbo_cross_cov(ppbo_ctx* ctx, int kernel_id, const double* d_X1, int n1, con
   dim3 grid((n2 + TS - 1) / TS, (n1 + TS - 1) / TS);
   const size_t lds = (size_t)2 * D * TS * sizeof(double);
   hipStream_t s = (hipStream_t)stream;
+  if (lds > 64 * 1024) {   // D up to 64 needs up to 64 KB + padding
+    ppbo_lds_limit(ctx, (const void*)crosscov_kernel<PPBO_KERNEL_SE>, 112 * 1024);
+    ppbo_lds_limit(ctx, (const void*)crosscov_kernel<PPBO_KERNEL_RQ>, 112 * 1024);
+  }
   switch (kernel_id) {
     case PPBO_KERNEL_SE: crosscov_kernel<PPBO_KERNEL_SE><<<grid, 256, lds, s>>>(d_X1, n1, d_X2, n2, D, p, d_K, ldk); break;
     case PPBO_KERNEL_RQ: crosscov_kernel<PPBO_KERNEL_RQ><<<grid, 256, lds, s>>>(d_X1, n1, d_X2, n2, D, p, d_K, ldk); break;

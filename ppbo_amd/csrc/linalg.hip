@@ -815,22 +815,12 @@ __global__ void set_int_kernel(int* p, int v, double* fail_pivot) {
 
 }  // namespace
 
-// 3 (default): potrf_step_kernel; 2: potf2_block + trsm_mfma + gemm64 SYRK
-static int potrf_gen() {
-  static int g = -1;
-  if (g < 0) { const char* e = getenv("PPBO_POTRF_GEN"); g = e ? atoi(e) : 3; }
-  return g;
-}
-
+// ctx->potrf_gen (PPBO_POTRF_GEN): 3 (default): potrf_step_kernel; 2: potf2_block + trsm_mfma + gemm64 SYRK
 int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hipStream_t s, double* d_fail_pivot) {
   PpboProfScope pf(ctx, ppbo_ctx::PF_POTRF, s);
   set_int_kernel<<<1, 1, 0, s>>>(d_info, 0, d_fail_pivot);
-  if (potrf_gen() >= 3) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)potrf_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
-      attr_done = true;
-    }
+  if (ctx->potrf_gen >= 3) {
+    ppbo_lds_limit(ctx, (const void*)potrf_step_kernel, STEP_LDS);
     const int npanel = (N + NB - 1) / NB;
     double* diag = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_POTRF, (size_t)npanel * NB * NB * sizeof(double));
     if (!diag) return (int)hipErrorOutOfMemory;
@@ -876,11 +866,7 @@ int ppbo_potrf_fail_bound_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl
                                 const double* d_fail_pivot, double* d_out, hipStream_t s) {
   const size_t lds = ((size_t)64 * 65 + 64 + N) * sizeof(double);
   if (lds > 150 * 1024) return 1;     // leading block too large for the LDS-resident right-hand side: no bound
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)potrf_fail_bound_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_done = true;
-  }
+  ppbo_lds_limit(ctx, (const void*)potrf_fail_bound_kernel, 150 * 1024);
   potrf_fail_bound_kernel<<<1, 512, lds, s>>>(d_L, ldl, d_info, d_fail_pivot, d_out);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
@@ -995,7 +981,7 @@ int ppbo_dot_async(ppbo_ctx* ctx, const double* d_x, const double* d_y, int N, d
 extern "C" {
 
 int ppbo_potrf(ppbo_ctx* ctx, double* d_A, int N, int lda, int* h_info, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_A && N > 0 && lda >= N, "matrix");
   hipStream_t s = (hipStream_t)stream;
   int* d_info = (int*)ppbo_workspace(ctx, ppbo_ctx::WS_SMALL, 4096);
@@ -1011,13 +997,13 @@ int ppbo_potrf(ppbo_ctx* ctx, double* d_A, int N, int lda, int* h_info, void* st
 
 int ppbo_dgemv(ppbo_ctx* ctx, int trans, int lower, int N, const double* d_A, int lda, const double* d_x,
                double* d_y, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_A && d_x && d_y && N > 0 && lda >= N, "arguments");
   return ppbo_gemv_async(ctx, d_A, N, lda, d_x, d_y, trans, lower, (hipStream_t)stream);
 }
 
 int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int* h_info, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_A && d_Ainv && N > 0, "matrix");
   hipStream_t s = (hipStream_t)stream;
   const size_t bytes = (size_t)N * N * sizeof(double);

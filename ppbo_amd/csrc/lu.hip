@@ -173,7 +173,7 @@ extern "C" {
 
 int ppbo_lu_slogdet(ppbo_ctx* ctx, double* d_A, int N, int lda, double* h_u_sign, double* h_u_logdet, int* h_info,
                     void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_A && N > 0 && lda >= N, "matrix");
   hipStream_t s = (hipStream_t)stream;
   double* d_out = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, 4 * sizeof(double) + ((size_t)N + 8) * sizeof(int));
@@ -211,7 +211,7 @@ int ppbo_lu_slogdet(ppbo_ctx* ctx, double* d_A, int N, int lda, double* h_u_sign
 
 int ppbo_laplace_logdet(ppbo_ctx* ctx, const double* d_Sigma, const double* d_lam_diag, const double* d_lam_off,
                         int N, int m, double* h_u_sign, double* h_u_logdet, int* h_info, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_Sigma && d_lam_diag && d_lam_off, "null pointer");
   PPBO_REQUIRE(ctx, N > 0 && m >= 1 && N % (m + 1) == 0, "sizes");
   hipStream_t s = (hipStream_t)stream;

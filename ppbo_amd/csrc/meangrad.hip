@@ -81,7 +81,7 @@ void launch_mean_grad(const ppbo_model* m, const KernParams& p, const double* d_
 
 extern "C" int ppbo_mean_grad(ppbo_ctx* ctx, const ppbo_model* m, const double* d_Xc, int64_t M, double* d_mu,
                               double* d_grad, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, m != nullptr && m->d_X && m->d_alpha, "model X/alpha");
   PPBO_REQUIRE(ctx, m->N > 0 && m->D > 0 && m->D <= 64, "model sizes (D<=64)");
   PPBO_REQUIRE(ctx, m->kernel_id >= 0 && m->kernel_id <= 2, "kernel_id");

@@ -221,18 +221,11 @@ template <class C, int MINW>
 int launch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, int ldk, int Mc, int mblk,
                     double* slab, hipStream_t s) {
   const size_t lds = C::LDS_DOUBLES * sizeof(double);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)quadform_kernel<C, MINW, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)quadform_kernel<C, MINW, false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  ppbo_lds_limit(ctx, (const void*)quadform_kernel<C, MINW, true>, (int)lds);
+  ppbo_lds_limit(ctx, (const void*)quadform_kernel<C, MINW, false>, (int)lds);
   const int ntm = (N + C::BM - 1) / C::BM, ntn = (Mc + C::BN - 1) / C::BN;
   const int grid = ntm * ntn;
-  static int order = -1;
-  if (order < 0) { const char* e = getenv("PPBO_QF_ORDER"); order = e ? atoi(e) : 258; }   // candidate-tile fastest in chunks of 64 tiles (measured best)
+  const int order = ctx->qf_order;   // PPBO_QF_ORDER; default 258 = candidate-tile fastest in chunks of 64 tiles (measured best)
   const int swz = ((grid % 8 == 0 && grid >= 64) ? (order & 1) : 0) | (order & ~1);
   // every tile in bounds, 16-byte aligned, and every K range a multiple of 16?
   const bool fast = (N % C::BM == 0) && (Mc % C::BN == 0) && (N % 2 == 0) && (ldk % 2 == 0) && (mblk % 16 == 0 || mblk == 1 || (C::BM % mblk == 0)) &&
@@ -243,19 +236,12 @@ int launch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, int
   return 0;
 }
 
-int quadform_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("PPBO_QF_VARIANT");
-    v = e ? atoi(e) : 2;   // measured best on MI355X: 8 waves of 32x64, 4 waves/SIMD
-    if (v < 0 || v > 5) v = 0;
-  }
-  return v;
-}
+// ctx->qf_variant (PPBO_QF_VARIANT); default 2 = measured best on MI355X: 8 waves of 32x64, 4 waves/SIMD
+int quadform_variant(const ppbo_ctx* ctx) { return ctx->qf_variant; }
 
 int dispatch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, int ldk, int Mc, int mblk,
                       double* slab, hipStream_t s) {
-  switch (quadform_variant()) {
+  switch (quadform_variant(ctx)) {
     case 1: return launch_quadform<QF1, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
     case 2: return launch_quadform<QF2, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
     case 3: return launch_quadform<QF3, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
@@ -427,7 +413,7 @@ extern "C" {
 int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
                  double mustar, double* d_mu, double* d_var, double* d_score, double* h_best_val,
                  int64_t* h_best_idx, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   if (int rc = check_model(ctx, model)) return rc;
   PPBO_REQUIRE(ctx, d_Xc != nullptr && M > 0, "candidates");
   PPBO_REQUIRE(ctx, score_kind >= 0 && score_kind <= 2, "score_kind");
@@ -439,7 +425,7 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
   const int N = model->N, mblk = model->m + 1, n_q = N / mblk;
   const int64_t chunk_cap = 65536;
   const int64_t n_chunks = (M + chunk_cap - 1) / chunk_cap;
-  const int qf_bm = (quadform_variant() == 5) ? 256 : 128;
+  const int qf_bm = (quadform_variant(ctx) == 5) ? 256 : 128;
   const int ntm = (N + qf_bm - 1) / qf_bm;   // slabs = row tiles of the shipped quadform shape
 
   // workspaces sized for the largest chunk
@@ -495,7 +481,7 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
 
 int ppbo_predict_cov(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int M, double shrink,
                      double* d_mu, double* d_cov, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   if (int rc = check_model(ctx, model)) return rc;
   PPBO_REQUIRE(ctx, d_Xc && d_cov && M > 0 && M <= 16384, "candidates (M <= 16384 for a full covariance)");
   PPBO_REQUIRE(ctx, model->d_G && model->d_lam_diag && model->d_lam_off, "model G/Lambda");
@@ -543,7 +529,7 @@ int ppbo_predict_cov(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc,
 int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, int B, int G, double shrink,
                   const double* d_z, int S, double mustar, double jitter, double* d_ei, double* d_varmax,
                   void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   if (int rc = check_model(ctx, model)) return rc;
   PPBO_REQUIRE(ctx, d_grid && d_z && B > 0 && G > 0 && G <= 128 && S > 0, "line arguments (G <= 128)");
   PPBO_REQUIRE(ctx, model->d_G && model->d_lam_diag && model->d_lam_off, "model G/Lambda");
@@ -565,7 +551,8 @@ int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
   if (!part) return (int)hipErrorOutOfMemory;
   double* mu = part + (size_t)n_split_eff * Bc_max * G;
   double* cov = mu + (size_t)Bc_max * G;
-  const size_t mc_lds = ((size_t)G * (G + 1) + G + 16) * sizeof(double);
+  const size_t mc_lds = ((size_t)G * (G + 1) + G + 16) * sizeof(double);   // G = 128: 133 KB of the CU's 160 KB
+  if (mc_lds > 64 * 1024) ppbo_lds_limit(ctx, (const void*)line_mc_kernel, (128 * 129 + 128 + 16) * (int)sizeof(double));
   for (int b0 = 0; b0 < B; b0 += Bc_max) {
     const int Bc = (B - b0 < Bc_max) ? (B - b0) : Bc_max;
     const int M = Bc * G;

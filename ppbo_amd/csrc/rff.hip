@@ -253,7 +253,7 @@ extern "C" {
 
 int ppbo_rff_project(ppbo_ctx* ctx, const double* d_X, int N, int D, const double* d_W, int F,
                      const double* d_b, double sigma_f, double* d_Phi, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_X && d_W && d_b && d_Phi, "null pointer");
   PPBO_REQUIRE(ctx, N > 0 && D > 0 && D <= 256 && F > 0, "sizes");
   const double scale = std::sqrt(2.0 * sigma_f * sigma_f / (double)F);
@@ -279,7 +279,7 @@ int ppbo_rff_project(ppbo_ctx* ctx, const double* d_X, int N, int D, const doubl
 int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const double* d_W, int F,
                    const double* d_b, double sigma_f, const double* d_omega, double* d_score,
                    double* h_best_val, int64_t* h_best_idx, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_Xc && d_W && d_b && d_omega, "null pointer");
   PPBO_REQUIRE(ctx, M > 0 && D > 0 && D <= 64 && F > 0, "sizes (D<=64)");
   hipStream_t s = (hipStream_t)stream;
@@ -334,7 +334,7 @@ int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const do
 
 int ppbo_rff_terms(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, double sigma,
                    const double* d_omega, double* h_S, double* d_grad, double* d_hdiag, void* stream) {
-  PPBO_REQUIRE(ctx, ctx != nullptr, "ctx");
+  PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_Phi && d_omega, "null pointer");
   PPBO_REQUIRE(ctx, F > 0 && N > 0 && m >= 1 && sigma > 0 && N % (m + 1) == 0, "sizes");
   hipStream_t s = (hipStream_t)stream;

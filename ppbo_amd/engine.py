@@ -45,8 +45,7 @@ class Engine:
         if not torch.cuda.is_available():
             raise RuntimeError("ppbo_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
         self.lib = _lib.load()
-        self.device = torch.device("cuda", device)
-        torch.cuda.set_device(self.device)
+        self.device = torch.device("cuda", device)   # every allocation / stream below names it explicitly
         ctx = C.c_void_p()
         rc = self.lib.ppbo_ctx_create(device, C.byref(ctx))
         if rc != 0:
@@ -291,11 +290,11 @@ class Engine:
         return ei, vm
 
     # ---- RFF -------------------------------------------------------------------------
-    def rff_project(self, X, W, b, sigma_f):
+    def rff_project(self, X, W, b, sigma_f, out=None):
         X, W, b = self.dev(X), self.dev(W), self.dev(b).reshape(-1)
         N, D = X.shape
         F = W.shape[0]
-        Phi = self.empty(F, N)
+        Phi = self.empty(F, N) if out is None else out
         rc = self.lib.ppbo_rff_project(self.ctx, _ptr(X), N, D, _ptr(W), F, _ptr(b), float(sigma_f), _ptr(Phi),
                                        self._stream())
         self._check(rc, "ppbo_rff_project")

@@ -287,10 +287,22 @@ class GPModel:
             else:
                 f0 = self.fMAP
             fm, st = self.eng.fit_fmap(self._dSigma_inv, f0, self.m, self.theta[0], gtol=gtol)
+            if not st["converged"] and not approx_optimization and st["gradnorm"] > 1e3 * gtol:
+                # the trust region stalled far from stationarity (no descent predicted / radius collapsed): the
+                # reference would hand back SciPy's last iterate; one fresh start from the prior is cheap here
+                print("---!!!--- f_MAP search stopped at |grad T| = " + str(st["gradnorm"]) + "; restarting from a prior draw")
+                fm2, st2 = self.eng.fit_fmap(self._dSigma_inv, self._draw_prior(), self.m, self.theta[0], gtol=gtol)
+                if st2["T"] > st["T"] or not np.isfinite(st["T"]):
+                    fm, st = fm2, st2
             if self.verbose:
                 print("... this took " + str(time.time() - start) + " seconds.")
             if st["T"] > best_T:
                 best_T, best, self.fit_stats = st["T"], fm, st
+        if best is None:        # every trial ended with a non-finite T: keep the previous estimate, like a failed minimize
+            print("---!!!--- f_MAP search produced no finite objective; keeping the previous f_MAP ---!!!---")
+            if self.fMAP is None or len(self.fMAP) != self.N:
+                self.fMAP = np.zeros(self.N)
+            best = self.eng.dev(self.fMAP)
         self.fMAP = best.cpu().numpy()
         # like the reference, the previous Lambda_MAP / posterior covariance stay in place until
         # update_model recomputes them (and survive a failed recomputation, gp_model.py:115-120)
