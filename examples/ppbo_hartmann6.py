@@ -4,6 +4,7 @@ with its hartmann6d setup :174-183): D initial coordinate queries, then PCD / EI
 simulated user who picks the best point on the projective line.
 
     python examples/ppbo_hartmann6.py --queries 30 --strategy PCD
+    python examples/ppbo_hartmann6.py --queries 30 --compare      # cold refits vs the incremental fit (f-4)
 """
 from __future__ import annotations
 
@@ -35,7 +36,7 @@ def user(xi, x, lo, hi):
     return float(al[np.argmin(hartmann6(al[:, None] * xi[None, :] + x[None, :]))])
 
 
-def run(queries=30, strategy="PCD", m=31, seed=0, verbose=False):
+def run(queries=30, strategy="PCD", m=31, seed=0, verbose=False, incremental=False):
     from ppbo_amd.acquisition import next_query
     from ppbo_amd.gp_model import GPModel
     from ppbo_amd.ppbo_settings import PPBO_settings
@@ -59,7 +60,7 @@ def run(queries=30, strategy="PCD", m=31, seed=0, verbose=False):
         a = user(xi, x, lo, hi)
         results = np.vstack([results, np.concatenate([a * xi + x, xi, [a]])])
         if gp is None:
-            gp = GPModel(st)
+            gp = GPModel(st, incremental=incremental)
         gp.update_feedback_processing_object(results)
         gp.update_data()
         gp.update_model()
@@ -73,12 +74,19 @@ def run(queries=30, strategy="PCD", m=31, seed=0, verbose=False):
         gp.update_feedback_processing_object(results)
         gp.mustar_previous_iteration = gp.mustar
         gp.update_data()
+        n_log = len(gp.fit_log)
+        t_q = time.time()
         gp.update_model()
+        t_q = time.time() - t_q
         fx = float(hartmann6(gp.FP.unscale(gp.xstar))[0])
-        hist.append(fx)
+        trials = gp.fit_log[n_log:]
+        hist.append(dict(fx=fx, N=gp.N, update_model_s=t_q, fit_s=sum(t["seconds"] for t in trials),
+                         iterations=sum(t["iterations"] for t in trials), n_cholesky=sum(t["n_cholesky"] for t in trials),
+                         trials=len(trials)))
         if verbose:
-            print(f"query {i + 1:3d}  N={gp.N:5d}  f(x*)={fx:+.4f}  fit iters={gp.fit_stats['iterations']:4d} "
-                  f"chol={gp.fit_stats['n_cholesky']:5d}  elapsed {time.time() - t0:6.1f}s")
+            h = hist[-1]
+            print(f"query {i + 1:3d}  N={gp.N:5d}  f(x*)={fx:+.4f}  fit: {h['trials']} start(s), {h['iterations']:4d} TR iterations, "
+                  f"{h['n_cholesky']:5d} factorizations, {h['fit_s'] * 1e3:8.1f} ms   elapsed {time.time() - t0:6.1f}s")
     return gp, hist
 
 
@@ -87,6 +95,18 @@ if __name__ == "__main__":
     ap.add_argument("--queries", type=int, default=30)
     ap.add_argument("--strategy", default="PCD")
     ap.add_argument("--m", type=int, default=31)
+    ap.add_argument("--incremental", action="store_true", help="bordered Sigma^-1 update + warm-started f_MAP (f-4)")
+    ap.add_argument("--compare", action="store_true", help="run cold and incremental back to back and summarise")
     args = ap.parse_args()
-    gp, hist = run(args.queries, args.strategy, args.m, verbose=True)
-    print("best f(x*) reached:", min(hist), "(global minimum -3.322)")
+    modes = [False, True] if args.compare else [args.incremental]
+    summary = {}
+    for inc in modes:
+        print(f"---- {'incremental' if inc else 'cold (reference semantics: prior draw per update)'} ----")
+        gp, hist = run(args.queries, args.strategy, args.m, verbose=True, incremental=inc)
+        body = hist[:-1] if len(hist) > 1 else hist            # the last query runs the reference's 10 random restarts
+        summary[inc] = dict(best=min(h["fx"] for h in hist), fit_ms=1e3 * np.mean([h["fit_s"] for h in body]),
+                            chol=np.mean([h["n_cholesky"] for h in body]), iters=np.mean([h["iterations"] for h in body]))
+        print("best f(x*) reached:", summary[inc]["best"], "(global minimum -3.322)")
+    for inc, s in summary.items():
+        print(f"{'incremental' if inc else 'cold       '}: mean per query (last excluded) fit {s['fit_ms']:8.1f} ms, "
+              f"{s['iters']:6.1f} TR iterations, {s['chol']:6.1f} factorizations; best f(x*) {s['best']:+.4f}")

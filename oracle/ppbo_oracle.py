@@ -389,6 +389,26 @@ def predict_mean_var(Xc, X, theta, alpha, A, kernel="SE_kernel"):
     return mu, var
 
 
+def mu_star(X, theta, Sigma_inv, f_map, kernel="SE_kernel", trials=3):
+    """mu_star (src/gp_model.py:415-437): SciPy differential evolution (updating='immediate', maxiter=2000,
+    global NumPy stream) on -mu_pred, `trials` times; distinct maxima (> 0.1 apart, :430) are collected.
+    Returns xstar[D], mustar, xstars_local[k, D]."""
+    D = X.shape[1]
+    neg = lambda x: -mu_pred(x, X, theta, Sigma_inv, f_map, kernel)     # noqa: E731
+    xstar = xloc = None
+    best = np.inf
+    for i in range(trials):
+        res = scipy.optimize.differential_evolution(neg, ((0, 1),) * D, updating="immediate", disp=False, maxiter=2000)
+        if i == 0:
+            xstar, best, xloc = res.x, res.fun, res.x.reshape(1, D)
+        else:
+            if all(np.linalg.norm(x - res.x) > 1e-1 for x in xloc):
+                xloc = np.vstack([xloc, res.x])
+            if res.fun < best:
+                best, xstar = res.fun, res.x
+    return xstar.reshape(D), mu_pred(xstar, X, theta, Sigma_inv, f_map, kernel), xloc
+
+
 def mean_grad(Xc, X, theta, alpha, kernel="SE_kernel"):
     """mu = K*' alpha and its gradient with respect to the (scaled) point.  The reference has no
     gradient function (mu_star maximises mu_pred by differential evolution, src/gp_model.py:415-437);
@@ -497,6 +517,29 @@ def rff_features(Xq, W, b, sigma_f):
 def rff_score(Xc, W, b, sigma_f, omega):
     """phi(x)' omega batched over candidates (src/random_fourier_sampler.py:166,170)."""
     return rff_features(Xc, W, b, sigma_f).T @ omega
+
+
+def rff_return_xstar(W, b, sigma_f, omega, xstars_local, min_trials=5, max_trials=30):
+    """Hsampler.return_xstar (src/random_fourier_sampler.py:143-176): L-BFGS-B on -phi(x)' omega from perturbed
+    posterior-mean maxima (global NumPy stream), best in-bounds result of at least `min_trials` starts."""
+    F, D = W.shape
+    c = math.sqrt(2.0 * sigma_f ** 2 / F)
+    phi = lambda x: c * np.cos(W @ x + b)                                   # noqa: E731  (:48-50)
+    dphi = lambda x: -c * (np.sin(W @ x + b)[:, None] * W)                  # noqa: E731  (:51-53)
+    fval, xstar, i = -1e10, None, 0
+    loc = np.atleast_2d(xstars_local)
+    while xstar is None or i < min_trials:
+        if i > max_trials:
+            break
+        i += 1
+        x0 = loc[np.random.randint(loc.shape[0])]
+        x0 = np.clip(x0 + 0.01 * np.random.uniform(0, 1, size=D), 0, 1)
+        res = scipy.optimize.minimize(lambda x: -float(phi(x) @ omega), x0=x0, method="L-BFGS-B", bounds=((0, 1),) * D,
+                                      jac=lambda x: -(dphi(x).T @ omega), options={"disp": False, "maxiter": 5000})
+        f = float(phi(res.x) @ omega)
+        if f > fval and np.all((res.x >= 0) & (res.x <= 1)):
+            fval, xstar = f, res.x
+    return xstar, fval
 
 
 def rff_terms(Phi, omega, m, sigma):

@@ -808,6 +808,21 @@ __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x,
   }
 }
 
+// borders of the appended inverse: out[0:n1, n1:] = -V, out[n1:, 0:n1] = -V^T, out[n1:, n1:] = Sinv (k x k)
+__global__ __launch_bounds__(256) void append_border_kernel(const double* __restrict__ V, const double* __restrict__ Sinv,
+                                                            int n1, int k, double* __restrict__ out, int ldo) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int c = threadIdx.x & 63;
+  if (i >= n1 + k || c >= k) return;
+  if (i < n1) {
+    const double v = -V[(size_t)i * k + c];
+    out[(size_t)i * ldo + n1 + c] = v;
+    out[(size_t)(n1 + c) * ldo + i] = v;
+  } else {
+    out[(size_t)i * ldo + n1 + c] = Sinv[(size_t)(i - n1) * k + c];
+  }
+}
+
 __global__ void set_int_kernel(int* p, int v, double* fail_pivot) {
   *p = v;
   if (fail_pivot) *fail_pivot = NAN;
@@ -1000,6 +1015,52 @@ int ppbo_dgemv(ppbo_ctx* ctx, int trans, int lower, int N, const double* d_A, in
   PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_A && d_x && d_y && N > 0 && lda >= N, "arguments");
   return ppbo_gemv_async(ctx, d_A, N, lda, d_x, d_y, trans, lower, (hipStream_t)stream);
+}
+
+int ppbo_pd_inverse_append(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, int N1, double* d_Ainv,
+                           int* h_info, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_A && d_A11inv && d_Ainv && N > 0, "matrix");
+  PPBO_REQUIRE(ctx, N1 > 0 && N1 < N && N - N1 <= 64, "append at most 64 rows to a non-empty block");
+  PPBO_REQUIRE(ctx, d_Ainv != d_A11inv, "in-place append is not supported");
+  hipStream_t s = (hipStream_t)stream;
+  const int k = N - N1;
+  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_APPEND, ((size_t)2 * N1 * k + 2 * (size_t)k * k) * sizeof(double));
+  if (!ws) return (int)hipErrorOutOfMemory;
+  double* U = ws;                         // [N1, k]  A11^-1 A12
+  double* V = U + (size_t)N1 * k;         // [N1, k]  U S^-1
+  double* S = V + (size_t)N1 * k;         // [k, k]   Schur complement A22 - A21 U
+  double* Si = S + (size_t)k * k;         // [k, k]   its inverse
+  const double* A12 = d_A + N1;           // rows 0..N1-1, columns N1..N-1 of A
+  if (h_info) *h_info = 0;
+  GemmArgs g{};
+  g.A = d_A11inv; g.lda = N1; g.B = A12; g.ldb = N; g.C = U; g.ldc = k;
+  g.M = N1; g.N = k; g.K = N1; g.alpha = 1.0; g.beta = 0.0; g.tri_block = 1;
+  if (int rc = ppbo_gemm_launch(ctx, g, 0, 0, s)) return rc;
+  PPBO_HIP_CHECK(ctx, hipMemcpy2DAsync(S, (size_t)k * sizeof(double), d_A + (size_t)N1 * N + N1, (size_t)N * sizeof(double),
+                                       (size_t)k * sizeof(double), k, hipMemcpyDeviceToDevice, s));
+  GemmArgs gs{};                          // S -= A12^T U
+  gs.A = A12; gs.lda = N; gs.B = U; gs.ldb = k; gs.C = S; gs.ldc = k;
+  gs.M = k; gs.N = k; gs.K = N1; gs.alpha = -1.0; gs.beta = 1.0; gs.tri_block = 1;
+  if (int rc = ppbo_gemm_launch(ctx, gs, 1, 0, s)) return rc;
+  int info = 0;
+  if (int rc = ppbo_pd_inverse(ctx, S, k, Si, &info, stream)) {
+    if (h_info) *h_info = info ? N1 + info : 0;
+    return rc;
+  }
+  GemmArgs gv{};                          // V = U S^-1
+  gv.A = U; gv.lda = k; gv.B = Si; gv.ldb = k; gv.C = V; gv.ldc = k;
+  gv.M = N1; gv.N = k; gv.K = k; gv.alpha = 1.0; gv.beta = 0.0; gv.tri_block = 1;
+  if (int rc = ppbo_gemm_launch(ctx, gv, 0, 0, s)) return rc;
+  PPBO_HIP_CHECK(ctx, hipMemcpy2DAsync(d_Ainv, (size_t)N * sizeof(double), d_A11inv, (size_t)N1 * sizeof(double),
+                                       (size_t)N1 * sizeof(double), N1, hipMemcpyDeviceToDevice, s));
+  GemmArgs gu{};                          // top-left block += V U^T
+  gu.A = V; gu.lda = k; gu.B = U; gu.ldb = k; gu.C = d_Ainv; gu.ldc = N;
+  gu.M = N1; gu.N = N1; gu.K = k; gu.alpha = 1.0; gu.beta = 1.0; gu.tri_block = 1;
+  if (int rc = ppbo_gemm_launch(ctx, gu, 0, 1, s)) return rc;
+  append_border_kernel<<<(N + 3) / 4, 256, 0, s>>>(V, Si, N1, k, d_Ainv, N);
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
 }
 
 int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int* h_info, void* stream) {

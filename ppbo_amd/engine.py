@@ -156,6 +156,17 @@ class Engine:
         self._check(rc, "ppbo_pd_inverse", info.value)
         return out
 
+    def pd_inverse_append(self, A, A11inv):
+        """Inverse of A[N,N] given the inverse of its leading N1 x N1 block (one appended query, f-4)."""
+        A, A11inv = self.dev(A), self.dev(A11inv)
+        N, N1 = A.shape[0], A11inv.shape[0]
+        out = self.empty(N, N)
+        info = C.c_int(0)
+        rc = self.lib.ppbo_pd_inverse_append(self.ctx, _ptr(A), N, _ptr(A11inv), N1, _ptr(out), C.byref(info),
+                                             self._stream())
+        self._check(rc, "ppbo_pd_inverse_append", info.value)
+        return out
+
     def dgemm(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, C_out=None):
         A, B = self.dev(A), self.dev(B)
         M = A.shape[1] if transA else A.shape[0]

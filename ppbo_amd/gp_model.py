@@ -27,12 +27,21 @@ from .feedback_processing import FeedbackProcessing
 SEARCH_CANDIDATES = 65536      # uniform candidates per mu_star trial
 ASCENT_STARTS = 32             # best well-separated candidates refined together on the device
 ASCENT_ITERS = 100             # cap on batched ascent iterations (one ppbo_mean_grad launch each)
+APPEND_REFRESH = 16            # incremental mode: bordered updates of Sigma^-1 between two full inversions
 
 
 class GPModel:
-    def __init__(self, PPBO_settings, engine=None):
+    def __init__(self, PPBO_settings, engine=None, incremental=False):
+        """incremental=True (not a reference feature): when update_data() has only appended one
+        query's m+1 rows (feedback_processing.py:133-154), Sigma^-1 is bordered instead of refactorised
+        (ppbo_pd_inverse_append) and f_MAP starts from the previous estimate padded with the previous posterior
+        mean at the new rows (the reference pads with the mean of f_MAP, gp_model.py:375-377, and only does so
+        during initialisation; its default is a fresh prior draw per update)."""
         self.COVARIANCE_SHRINKAGE = 1e-6            # gp_model.py:26
         self.eng = engine if engine is not None else get_engine()
+        self.incremental = bool(incremental)
+        self._sinv_state = None      # (X copy, theta tuple, appends since the last full inversion) behind _dSigma_inv
+        self.fit_log = []            # one dict per update_fMAP trial: iterations, n_cholesky, warm, seconds
         s = PPBO_settings
         self.verbose = s.verbose
         self.FP = None
@@ -54,6 +63,7 @@ class GPModel:
         self.fMAP_finding_trials = 1
         self.fMAP_optimizer = s.fMAP_optimizer
         self.fMAP_random_initial_vector = True
+        self.fMAP_gtol = 1e-4                       # SciPy trust-exact default, which the reference inherits (gp_model.py:382-384)
         self.mustar_finding_trials = s.mustar_finding_trials
         self.mustar_previous_iteration = 0
         self.mustar = None
@@ -160,7 +170,20 @@ class GPModel:
         self._invalidate("Sigma")
 
     def update_Sigma_inv(self, theta):
-        self._dSigma_inv = self.eng.pd_inverse(self._dSigma)
+        th = tuple(float(t) for t in theta)
+        st = self._sinv_state
+        done = False
+        if (self.incremental and st is not None and st[1] == th and st[2] < APPEND_REFRESH
+                and 0 < self.N - st[0].shape[0] <= 64 and np.array_equal(self.X[:st[0].shape[0]], st[0])):
+            try:
+                self._dSigma_inv = self.eng.pd_inverse_append(self._dSigma, self._dSigma_inv)
+                self._sinv_state = (self.X.copy(), th, st[2] + 1)
+                done = True
+            except NotPositiveDefinite:
+                pass                      # Schur complement lost definiteness to rounding: full inversion below
+        if not done:
+            self._dSigma_inv = self.eng.pd_inverse(self._dSigma)
+            self._sinv_state = (self.X.copy(), th, 0)
         self._invalidate("Sigma_inv", "Pinv")
 
     def set_theta(self):
@@ -274,19 +297,36 @@ class GPModel:
     def update_fMAP(self, random_initial_vector=None, fmap_finding_trials=None, approx_optimization=False):
         trials = self.fMAP_finding_trials if fmap_finding_trials is None else fmap_finding_trials
         rnd = self.fMAP_random_initial_vector if random_initial_vector is None else random_initial_vector
-        gtol = 100.0 if approx_optimization else 1e-4          # gp_model.py:365-368 (SciPy default gtol)
+        gtol = 100.0 if approx_optimization else self.fMAP_gtol   # gp_model.py:365-368 (SciPy default gtol 1e-4)
         if self.verbose:
             print("MAP-estimation begins...")
         start = time.time()
         best_T, best = -np.inf, None
+        # incremental mode: one warm start replaces the reference's default prior draw (not on the last
+        # iteration, whose 10 random restarts are the reference's guard against local optima, gp_model.py:96-97)
+        warm = (self.incremental and self.fMAP is not None and len(self.fMAP) <= self.N and not self.last_iteration
+                and random_initial_vector is None and fmap_finding_trials is None)
+        if warm:
+            rnd, trials = False, 1
         for _ in range(trials):
+            t_trial = time.time()
             if self.fMAP is None or rnd or len(self.fMAP) > self.N:
                 f0 = self._draw_prior()
-            elif len(self.fMAP) < self.N:                        # pad with the mean (gp_model.py:375-377)
-                f0 = np.concatenate([self.fMAP, np.full(self.N - len(self.fMAP), np.mean(self.fMAP))])
+            elif len(self.fMAP) < self.N:
+                n_old = len(self.fMAP)
+                pm = self._post_mean
+                if warm and pm is not None and pm.X.shape[0] == n_old:
+                    # previous posterior mean at the appended rows: K(X_new, X_old) alpha_old
+                    pad = self.eng.predict(pm, self.X[n_old:], score=SCORE_MEAN, want_var=False,
+                                           want_best=False)["mu"].cpu().numpy()
+                else:                                            # pad with the mean (gp_model.py:375-377)
+                    pad = np.full(self.N - n_old, np.mean(self.fMAP))
+                f0 = np.concatenate([self.fMAP, pad])
             else:
                 f0 = self.fMAP
             fm, st = self.eng.fit_fmap(self._dSigma_inv, f0, self.m, self.theta[0], gtol=gtol)
+            self.fit_log.append(dict(N=self.N, iterations=st["iterations"], n_cholesky=st["n_cholesky"],
+                                     converged=st["converged"], warm=bool(warm), seconds=time.time() - t_trial))
             if not st["converged"] and not approx_optimization and st["gradnorm"] > 1e3 * gtol:
                 # the trust region stalled far from stationarity (no descent predicted / radius collapsed): the
                 # reference would hand back SciPy's last iterate; one fresh start from the prior is cheap here

@@ -25,8 +25,11 @@ def load_golden(name):
 def golden_names(pred=lambda n: True):
     if not os.path.isdir(GOLDEN):
         return []
+    # model fixtures only: `<cfg>_x.npz` (round-2 extras on <cfg>'s model state) and `g7.npz` (the C1 trace)
+    # are loaded by name where they are used
     return sorted(f[:-4] for f in os.listdir(GOLDEN)
-                  if f.endswith(".npz") and not f.startswith("_") and pred(f[:-4]))
+                  if f.endswith(".npz") and not f.startswith("_") and not f.endswith("_x.npz") and f != "g7.npz"
+                  and pred(f[:-4]))
 
 
 @pytest.fixture(scope="session")

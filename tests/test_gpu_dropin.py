@@ -225,4 +225,4 @@ def test_hartmann6_loop_reaches_the_optimum():
     from ppbo_hartmann6 import run
     gp, hist = run(queries=16, strategy="PCD", m=31, seed=0)
     assert gp.N == (6 + 16) * 32
-    assert min(hist) <= -3.0, hist
+    assert min(h["fx"] for h in hist) <= -3.0, hist

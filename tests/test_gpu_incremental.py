@@ -1,0 +1,105 @@
+"""the incremental fit -- bordered Sigma^-1 when one query is appended
+(feedback_processing.py:133-154) and the warm-started f_MAP -- against the full refit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from ppbo_amd.engine import get_engine
+    return get_engine(0)
+
+
+@pytest.mark.parametrize("name", ["smoke", "c2", "c3"])
+def test_bordered_inverse_matches_full_inverse(eng, golden, name):
+    """Append the fixture's queries one at a time from half the design: the bordered inverse must act like the
+    full one (residual |Sigma Sigma^-1 - I| of the same size, Sigma^-1 f equal to the cond(Sigma) * eps floor)."""
+    g = golden(name)
+    X, th, m, kern = g["X"], g["theta"], int(g["m"]), str(g["kernel"])
+    mb = m + 1
+    N = X.shape[0]
+    n_q = N // mb
+    q0 = max(1, n_q // 2)
+    Xd = eng.dev(X)
+    Sinv = eng.pd_inverse(eng.gram(Xd[:q0 * mb], th, kern))
+    for q in range(q0, n_q):
+        Sig = eng.gram(Xd[:(q + 1) * mb], th, kern)
+        Sinv = eng.pd_inverse_append(Sig, Sinv)
+    full = eng.pd_inverse(Sig)
+    Sg, A, B = Sig.cpu().numpy(), Sinv.cpu().numpy(), full.cpu().numpy()
+    I = np.eye(N)
+    res_app, res_full = np.abs(Sg @ A - I).max(), np.abs(Sg @ B - I).max()
+    assert res_app <= 20 * res_full + 1e-9, (res_app, res_full)
+    f = g["fMAP"]
+    a_app, a_full = A @ f, B @ f
+    assert np.abs(a_app - a_full).max() <= 1e-6 * np.abs(a_full).max()
+    assert np.abs(A - A.T).max() <= 1e-9 * np.abs(A).max()
+    # and the fit started from the same vector lands on the same f_MAP
+    f1, _ = eng.fit_fmap(Sinv, g["f_init"], m, th[0], gtol=1e-6)
+    f2, _ = eng.fit_fmap(full, g["f_init"], m, th[0], gtol=1e-6)
+    assert np.abs(f1.cpu().numpy() - f2.cpu().numpy()).max() <= 1e-5 * np.abs(g["fMAP"]).max()
+
+
+def test_append_rejects_bad_arguments(eng):
+    A = eng.dev(np.eye(8))
+    with pytest.raises(RuntimeError):
+        eng.pd_inverse_append(A, eng.dev(np.eye(8)))          # nothing appended
+    with pytest.raises(RuntimeError):
+        eng.pd_inverse_append(eng.dev(np.eye(200)), eng.dev(np.eye(100)))   # more than 64 rows at once
+
+
+def test_append_reports_indefinite_border(eng):
+    from ppbo_amd.engine import NotPositiveDefinite
+    A = np.eye(6)
+    A[5, 5] = -1.0
+    with pytest.raises(NotPositiveDefinite):
+        eng.pd_inverse_append(eng.dev(A), eng.dev(np.eye(4)))
+
+
+def _replay(golden, incremental, gtol=1e-8):
+    """Feed the reference's own C1 queries (fixture g7) to the drop-in, one at a time.  The global NumPy stream is
+    re-seeded before every design update and every fit, so cold and incremental runs see identical designs."""
+    from ppbo_amd.gp_model import GPModel
+    from ppbo_amd.ppbo_settings import PPBO_settings
+    g = golden("g7")
+    st = PPBO_settings(D=2, bounds=tuple(map(tuple, g["bounds"])), xi_acquisition_function="PCD", m=int(g["m"]),
+                       theta_initial=list(map(float, g["theta"])), verbose=False)
+    gp = GPModel(st, incremental=incremental)
+    gp.fMAP_gtol = gtol          # both runs to the optimum itself, not to SciPy's default gradient tolerance
+    n_init = int(g["n_init"])
+    out = []
+    for i in range(g["X_obs"].shape[0]):
+        if i == n_init - 1:
+            gp.turn_initialization_off()
+        np.random.seed(1000 + i)
+        gp.update_feedback_processing_object(g["X_obs"][:i + 1])
+        gp.update_data()
+        n_log = len(gp.fit_log)
+        np.random.seed(2000 + i)
+        gp.update_model()
+        out.append(dict(N=gp.N, fMAP=gp.fMAP.copy(), mustar=gp.mustar, xstar=gp.xstar.copy(),
+                        chol=sum(t["n_cholesky"] for t in gp.fit_log[n_log:]),
+                        iters=sum(t["iterations"] for t in gp.fit_log[n_log:]), X=gp.X.copy()))
+    return g, out
+
+
+def test_incremental_replay_matches_cold_refits(golden):
+    """Same queries and designs, cold (a prior draw per update, the reference's default) vs incremental (bordered
+    Sigma^-1, warm start): identical f_MAP to 1e-5 max|f| at every non-initial query, >= 3x fewer factorizations."""
+    g, cold = _replay(golden, False)
+    g, inc = _replay(golden, True)
+    n_init = int(g["n_init"])
+    ratio = []
+    for i in range(n_init, len(cold)):
+        assert np.array_equal(cold[i]["X"], inc[i]["X"])
+        scale = np.abs(cold[i]["fMAP"]).max()
+        assert np.abs(cold[i]["fMAP"] - inc[i]["fMAP"]).max() <= 1e-5 * scale, (i, cold[i]["N"])
+        assert abs(cold[i]["mustar"] - inc[i]["mustar"]) <= 1e-5 * max(abs(cold[i]["mustar"]), 1e-3)
+        ratio.append(cold[i]["chol"] / max(inc[i]["chol"], 1))
+    print("factorizations per query cold/incremental:", [(c["chol"], k["chol"]) for c, k in zip(cold[n_init:], inc[n_init:])])
+    assert np.mean(ratio) >= 3.0, ratio

@@ -111,3 +111,36 @@ def test_batched_ascent_and_polish_host_logic():
     assert np.abs(pgp).max() < 1e-5 * max(1.0, np.abs(alpha).max())
     # most starts are already close to stationary after the batched ascent
     assert np.median(np.abs(pg).max(axis=1)) < 1e-2 * np.abs(g1).max() + 1e-6
+
+
+# ---- the next_query dispatcher against the reference's own outputs (tools/make_golden_r2.py) -----------------
+@pytest.mark.parametrize("name", ["smoke", "rq", "c2", "c4", "c3"])
+@pytest.mark.parametrize("acq,xacq", [("PCD", "exploit"), ("EXT", "exploit"), ("RAND", "exploit"), ("RAND", "random"),
+                                      ("PCD", "random")])
+def test_next_query_matches_reference_outputs(name, acq, xacq):
+    """acquisition.py:9-65 with the reference's x* and a seeded global stream: identical xi, x (unscaled, zeros
+    retained, xi normalised by its max) and identical dim_query_prev_iter bookkeeping, call after call (the PCD /
+    EXT cycle wraps after D calls).  No GPU: these strategies only read GP_model.xstar and FP.unscale."""
+    import os
+    from types import SimpleNamespace
+    from conftest import GOLDEN, load_golden
+    if not os.path.exists(os.path.join(GOLDEN, f"{name}_x.npz")):
+        pytest.skip(f"{name}_x.npz not generated")
+    from ppbo_amd.acquisition import next_query
+    x, g = load_golden(name + "_x"), load_golden(name)
+    D = int(g["D"])
+    bounds = tuple(map(tuple, g["bounds"]))
+    st = PPBO_settings(D=D, bounds=bounds, xi_acquisition_function=acq, theta_initial=list(g["theta"]), m=int(g["m"]),
+                       verbose=False, kernel=str(g["kernel"]))
+    st.x_acquisition_function = xacq
+    fp = FeedbackProcessing(D, int(g["m"]), bounds, "equispaced", 0.4)
+    gp = SimpleNamespace(xstar=x["xstar"].copy(), FP=fp, verbose=False, D=D)
+    key = f"nq_{acq}_{xacq}"
+    for k in range(x[key + "_xi"].shape[0]):
+        np.random.seed(500 + k)
+        xi, xx = next_query(st, gp, unscale=True)
+        assert np.abs(xi - x[key + "_xi"][k]).max() <= 1e-12 * max(1.0, np.abs(x[key + "_xi"][k]).max()), (k, xi)
+        assert np.abs(xx - x[key + "_x"][k]).max() <= 1e-12 * max(1.0, np.abs(x[key + "_x"][k]).max()), (k, xx)
+        assert np.array_equal(xi == 0, x[key + "_xi"][k] == 0) and np.array_equal(xx == 0, x[key + "_x"][k] == 0)
+        assert int(getattr(st, "dim_query_prev_iter", -1)) == int(x[key + "_dim"][k])
+    assert np.array_equal(gp.xstar, x["xstar"])                 # the dispatcher must not mutate the model's x*
