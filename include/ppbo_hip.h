@@ -84,16 +84,24 @@ int ppbo_cross_cov(ppbo_ctx* ctx, int kernel_id, const double* d_X1, int n1,
 int ppbo_potrf(ppbo_ctx* ctx, double* d_A, int N, int lda, int* h_info, void* stream);
 int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int* h_info, void* stream);
 
+/* ppbo_pd_inverse that also hands out L^-1 (A = L L^T, full matrix, zeros above the diagonal); d_Linv may be NULL */
+int ppbo_pd_inverse_factors(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, double* d_Linv, int* h_info,
+                            void* stream);
+
 /* ---- f-4: the inverse after one query has been appended --------------------------------
  * FeedbackProcessing.update_X (src/feedback_processing.py:133-154) only ever APPENDS the m+1 rows of the
  * new query, so Sigma_new = [[Sigma_old, B], [B^T, C]] with Sigma_old unchanged.  Instead of the reference's
- * full refactorisation (update_Sigma_inv -> pd_inverse, src/gp_model.py:161-162) the inverse is bordered:
- *   U = Sigma_old^-1 B,  S = C - B^T U (Schur complement, k x k, k = N - N1 <= 64),
- *   Sigma_new^-1 = [[Sigma_old^-1 + U S^-1 U^T, -U S^-1], [-S^-1 U^T, S^-1]].
- * d_A[N,N] is the new matrix, d_A11inv[N1,N1] (row stride N1) the inverse of its leading block,
- * d_Ainv[N,N] the result.  PPBO_ERR_NOT_PD (info = failing column of A) when S is not positive definite. */
-int ppbo_pd_inverse_append(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, int N1,
-                           double* d_Ainv, int* h_info, void* stream);
+ * full refactorisation (update_Sigma_inv -> pd_inverse, src/gp_model.py:161-162) the Cholesky factor is
+ * bordered and the inverse follows from it -- through L^-1 (condition sqrt(cond Sigma)), never through
+ * Sigma_old^-1 B (bordering the explicit inverse loses cond(Sigma) * eps relative to the tiny Schur complement):
+ *   Y = L11^-1 B,  S = C - Y^T Y = L22 L22^T,  X = L22^-1 Y^T L11^-1  (k x N1, k = N - N1 <= 64),
+ *   L_new^-1 = [[L11^-1, 0], [-X, L22^-1]],
+ *   Sigma_new^-1 = [[Sigma_old^-1 + X^T X, -X^T L22^-1], [-L22^-T X, L22^-T L22^-1]].
+ * d_A[N,N] is the new matrix; d_A11inv / d_L11inv [N1,N1] (row stride N1) the inverse of its leading block and of
+ * that block's Cholesky factor (from ppbo_pd_inverse_factors or a previous append); d_Ainv / d_Linv [N,N] the
+ * results.  PPBO_ERR_NOT_PD (info = failing column of A) when S is not positive definite. */
+int ppbo_pd_inverse_append(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, const double* d_L11inv,
+                           int N1, double* d_Ainv, double* d_Linv, int* h_info, void* stream);
 
 /* ---- K5: Laplace terms of the projective-preference likelihood -----------
  * replaces sum_Phi/sum_Phi_vec (src/gp_model.py:176-218), the likelihood part of

@@ -51,7 +51,8 @@ SIGNATURES = {
     "ppbo_cross_cov": [_vp, _i, _vp, _i, _vp, _i, _i, _dp3, _vp, _i, _vp],
     "ppbo_potrf": [_vp, _vp, _i, _i, C.POINTER(_i), _vp],
     "ppbo_pd_inverse": [_vp, _vp, _i, _vp, C.POINTER(_i), _vp],
-    "ppbo_pd_inverse_append": [_vp, _vp, _i, _vp, _i, _vp, C.POINTER(_i), _vp],
+    "ppbo_pd_inverse_factors": [_vp, _vp, _i, _vp, _vp, C.POINTER(_i), _vp],
+    "ppbo_pd_inverse_append": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_laplace_terms": [_vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp],
     "ppbo_fit_fmap": [_vp, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
     "ppbo_T_and_grad": [_vp, _vp, _vp, _i, _i, _d, C.POINTER(_d), _vp, _vp],

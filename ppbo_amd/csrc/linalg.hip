@@ -808,18 +808,25 @@ __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x,
   }
 }
 
-// borders of the appended inverse: out[0:n1, n1:] = -V, out[n1:, 0:n1] = -V^T, out[n1:, n1:] = Sinv (k x k)
-__global__ __launch_bounds__(256) void append_border_kernel(const double* __restrict__ V, const double* __restrict__ Sinv,
-                                                            int n1, int k, double* __restrict__ out, int ldo) {
+// borders of the appended inverses (n = n1 + k):
+//   Ainv[0:n1, n1:] = -W, Ainv[n1:, 0:n1] = -W^T, Ainv[n1:, n1:] = BR
+//   Linv[0:n1, n1:] = 0,  Linv[n1:, 0:n1] = -X,   Linv[n1:, n1:] = L22i
+__global__ __launch_bounds__(256) void append_border_kernel(const double* __restrict__ W, const double* __restrict__ BR,
+                                                            const double* __restrict__ X, const double* __restrict__ L22i,
+                                                            int n1, int k, double* __restrict__ Ainv,
+                                                            double* __restrict__ Linv, int ld) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int c = threadIdx.x & 63;
   if (i >= n1 + k || c >= k) return;
   if (i < n1) {
-    const double v = -V[(size_t)i * k + c];
-    out[(size_t)i * ldo + n1 + c] = v;
-    out[(size_t)(n1 + c) * ldo + i] = v;
+    const double w = -W[(size_t)i * k + c];
+    Ainv[(size_t)i * ld + n1 + c] = w;
+    Ainv[(size_t)(n1 + c) * ld + i] = w;
+    Linv[(size_t)i * ld + n1 + c] = 0.0;
+    Linv[(size_t)(n1 + c) * ld + i] = -X[(size_t)c * n1 + i];
   } else {
-    out[(size_t)i * ldo + n1 + c] = Sinv[(size_t)(i - n1) * k + c];
+    Ainv[(size_t)i * ld + n1 + c] = BR[(size_t)(i - n1) * k + c];
+    Linv[(size_t)i * ld + n1 + c] = L22i[(size_t)(i - n1) * k + c];
   }
 }
 
@@ -1017,60 +1024,68 @@ int ppbo_dgemv(ppbo_ctx* ctx, int trans, int lower, int N, const double* d_A, in
   return ppbo_gemv_async(ctx, d_A, N, lda, d_x, d_y, trans, lower, (hipStream_t)stream);
 }
 
-int ppbo_pd_inverse_append(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, int N1, double* d_Ainv,
-                           int* h_info, void* stream) {
+int ppbo_pd_inverse_append(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, const double* d_L11inv,
+                           int N1, double* d_Ainv, double* d_Linv, int* h_info, void* stream) {
   PPBO_ENTER(ctx);
-  PPBO_REQUIRE(ctx, d_A && d_A11inv && d_Ainv && N > 0, "matrix");
+  PPBO_REQUIRE(ctx, d_A && d_A11inv && d_L11inv && d_Ainv && d_Linv && N > 0, "matrix");
   PPBO_REQUIRE(ctx, N1 > 0 && N1 < N && N - N1 <= 64, "append at most 64 rows to a non-empty block");
-  PPBO_REQUIRE(ctx, d_Ainv != d_A11inv, "in-place append is not supported");
+  PPBO_REQUIRE(ctx, d_Ainv != d_A11inv && d_Linv != d_L11inv, "in-place append is not supported");
   hipStream_t s = (hipStream_t)stream;
   const int k = N - N1;
-  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_APPEND, ((size_t)2 * N1 * k + 2 * (size_t)k * k) * sizeof(double));
+  const size_t nk = (size_t)N1 * k, kk = (size_t)k * k;
+  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_APPEND, (4 * nk + 3 * kk) * sizeof(double));
   if (!ws) return (int)hipErrorOutOfMemory;
-  double* U = ws;                         // [N1, k]  A11^-1 A12
-  double* V = U + (size_t)N1 * k;         // [N1, k]  U S^-1
-  double* S = V + (size_t)N1 * k;         // [k, k]   Schur complement A22 - A21 U
-  double* Si = S + (size_t)k * k;         // [k, k]   its inverse
-  const double* A12 = d_A + N1;           // rows 0..N1-1, columns N1..N-1 of A
+  double* Y = ws;            // [N1, k]  L11^-1 A12   (= L21^T of the bordered factor)
+  double* Z = Y + nk;        // [k, N1]  Y^T L11^-1
+  double* X = Z + nk;        // [k, N1]  L22^-1 Z     (-X is the new bottom-left block of L^-1)
+  double* Wm = X + nk;       // [N1, k]  X^T L22^-1   (-Wm is the new border of A^-1)
+  double* S = Wm + nk;       // [k, k]   Schur complement A22 - Y^T Y  ->  L22 (in place)
+  double* L22i = S + kk;     // [k, k]   L22^-1
+  double* BR = L22i + kk;    // [k, k]   L22^-T L22^-1
+  const double* A12 = d_A + N1;          // rows 0..N1-1, columns N1..N-1 of A
   if (h_info) *h_info = 0;
-  GemmArgs g{};
-  g.A = d_A11inv; g.lda = N1; g.B = A12; g.ldb = N; g.C = U; g.ldc = k;
-  g.M = N1; g.N = k; g.K = N1; g.alpha = 1.0; g.beta = 0.0; g.tri_block = 1;
-  if (int rc = ppbo_gemm_launch(ctx, g, 0, 0, s)) return rc;
+  auto gemm = [&](const double* A, int lda, int ta, const double* B, int ldb, int tb, double* C, int ldc, int M, int Nn,
+                  int K, double alpha, double beta) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = Nn; g.K = K; g.alpha = alpha; g.beta = beta; g.tri_block = 1;
+    return ppbo_gemm_launch(ctx, g, ta, tb, s);
+  };
+  if (int rc = gemm(d_L11inv, N1, 0, A12, N, 0, Y, k, N1, k, N1, 1.0, 0.0)) return rc;          // Y = L11^-1 A12
   PPBO_HIP_CHECK(ctx, hipMemcpy2DAsync(S, (size_t)k * sizeof(double), d_A + (size_t)N1 * N + N1, (size_t)N * sizeof(double),
                                        (size_t)k * sizeof(double), k, hipMemcpyDeviceToDevice, s));
-  GemmArgs gs{};                          // S -= A12^T U
-  gs.A = A12; gs.lda = N; gs.B = U; gs.ldb = k; gs.C = S; gs.ldc = k;
-  gs.M = k; gs.N = k; gs.K = N1; gs.alpha = -1.0; gs.beta = 1.0; gs.tri_block = 1;
-  if (int rc = ppbo_gemm_launch(ctx, gs, 1, 0, s)) return rc;
+  if (int rc = gemm(Y, k, 1, Y, k, 0, S, k, k, k, N1, -1.0, 1.0)) return rc;                    // S = A22 - Y^T Y
   int info = 0;
-  if (int rc = ppbo_pd_inverse(ctx, S, k, Si, &info, stream)) {
+  if (int rc = ppbo_potrf(ctx, S, k, k, &info, stream)) {
     if (h_info) *h_info = info ? N1 + info : 0;
     return rc;
   }
-  GemmArgs gv{};                          // V = U S^-1
-  gv.A = U; gv.lda = k; gv.B = Si; gv.ldb = k; gv.C = V; gv.ldc = k;
-  gv.M = N1; gv.N = k; gv.K = k; gv.alpha = 1.0; gv.beta = 0.0; gv.tri_block = 1;
-  if (int rc = ppbo_gemm_launch(ctx, gv, 0, 0, s)) return rc;
+  if (int rc = ppbo_trtri_async(ctx, S, k, k, L22i, k, s)) return rc;
+  if (int rc = gemm(Y, k, 1, d_L11inv, N1, 0, Z, N1, k, N1, N1, 1.0, 0.0)) return rc;           // Z = Y^T L11^-1
+  if (int rc = gemm(L22i, k, 0, Z, N1, 0, X, N1, k, N1, k, 1.0, 0.0)) return rc;                // X = L22^-1 Z
+  if (int rc = gemm(X, N1, 1, L22i, k, 0, Wm, k, N1, k, k, 1.0, 0.0)) return rc;                // W = X^T L22^-1
+  if (int rc = gemm(L22i, k, 1, L22i, k, 0, BR, k, k, k, k, 1.0, 0.0)) return rc;               // BR = L22^-T L22^-1
+  // A^-1: top-left = A11^-1 + X^T X, borders -W / -W^T, corner BR
   PPBO_HIP_CHECK(ctx, hipMemcpy2DAsync(d_Ainv, (size_t)N * sizeof(double), d_A11inv, (size_t)N1 * sizeof(double),
                                        (size_t)N1 * sizeof(double), N1, hipMemcpyDeviceToDevice, s));
-  GemmArgs gu{};                          // top-left block += V U^T
-  gu.A = V; gu.lda = k; gu.B = U; gu.ldb = k; gu.C = d_Ainv; gu.ldc = N;
-  gu.M = N1; gu.N = N1; gu.K = k; gu.alpha = 1.0; gu.beta = 1.0; gu.tri_block = 1;
-  if (int rc = ppbo_gemm_launch(ctx, gu, 0, 1, s)) return rc;
-  append_border_kernel<<<(N + 3) / 4, 256, 0, s>>>(V, Si, N1, k, d_Ainv, N);
+  if (int rc = gemm(X, N1, 1, X, N1, 0, d_Ainv, N, N1, N1, k, 1.0, 1.0)) return rc;
+  // L^-1: top-left = L11^-1, top-right 0, bottom-left -X, corner L22^-1
+  PPBO_HIP_CHECK(ctx, hipMemcpy2DAsync(d_Linv, (size_t)N * sizeof(double), d_L11inv, (size_t)N1 * sizeof(double),
+                                       (size_t)N1 * sizeof(double), N1, hipMemcpyDeviceToDevice, s));
+  append_border_kernel<<<(N + 3) / 4, 256, 0, s>>>(Wm, BR, X, L22i, N1, k, d_Ainv, d_Linv, N);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
 
-int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int* h_info, void* stream) {
+int ppbo_pd_inverse_factors(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, double* d_Linv, int* h_info,
+                            void* stream) {
   PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_A && d_Ainv && N > 0, "matrix");
   hipStream_t s = (hipStream_t)stream;
   const size_t bytes = (size_t)N * N * sizeof(double);
   double* L = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG, 2 * bytes);
   if (!L) return (int)hipErrorOutOfMemory;
-  double* Li = L + (size_t)N * N;
+  double* Li = d_Linv ? d_Linv : L + (size_t)N * N;
   PPBO_HIP_CHECK(ctx, hipMemcpyAsync(L, d_A, bytes, hipMemcpyDeviceToDevice, s));
   int info = 0;
   if (int rc = ppbo_potrf(ctx, L, N, N, &info, stream)) {
@@ -1083,6 +1098,10 @@ int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int
   g.A = Li; g.lda = N; g.B = Li; g.ldb = N; g.C = d_Ainv; g.ldc = N;
   g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0; g.klo_mode = 1; g.tri_block = 1;
   return ppbo_gemm_launch(ctx, g, 1, 0, s);
+}
+
+int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int* h_info, void* stream) {
+  return ppbo_pd_inverse_factors(ctx, d_A, N, d_Ainv, nullptr, h_info, stream);
 }
 
 }  // extern "C"

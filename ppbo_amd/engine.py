@@ -156,16 +156,26 @@ class Engine:
         self._check(rc, "ppbo_pd_inverse", info.value)
         return out
 
-    def pd_inverse_append(self, A, A11inv):
-        """Inverse of A[N,N] given the inverse of its leading N1 x N1 block (one appended query, f-4)."""
-        A, A11inv = self.dev(A), self.dev(A11inv)
-        N, N1 = A.shape[0], A11inv.shape[0]
-        out = self.empty(N, N)
+    def pd_inverse_factors(self, A):
+        """(A^-1, L^-1) with A = L L^T: what pd_inverse_append borders."""
+        A = self.dev(A)
+        N = A.shape[0]
+        out, linv = self.empty(N, N), self.empty(N, N)
         info = C.c_int(0)
-        rc = self.lib.ppbo_pd_inverse_append(self.ctx, _ptr(A), N, _ptr(A11inv), N1, _ptr(out), C.byref(info),
-                                             self._stream())
+        rc = self.lib.ppbo_pd_inverse_factors(self.ctx, _ptr(A), N, _ptr(out), _ptr(linv), C.byref(info), self._stream())
+        self._check(rc, "ppbo_pd_inverse_factors", info.value)
+        return out, linv
+
+    def pd_inverse_append(self, A, A11inv, L11inv):
+        """(A^-1, L^-1) of A[N,N] given those of its leading N1 x N1 block (one appended query, f-4)."""
+        A, A11inv, L11inv = self.dev(A), self.dev(A11inv), self.dev(L11inv)
+        N, N1 = A.shape[0], A11inv.shape[0]
+        out, linv = self.empty(N, N), self.empty(N, N)
+        info = C.c_int(0)
+        rc = self.lib.ppbo_pd_inverse_append(self.ctx, _ptr(A), N, _ptr(A11inv), _ptr(L11inv), N1, _ptr(out), _ptr(linv),
+                                             C.byref(info), self._stream())
         self._check(rc, "ppbo_pd_inverse_append", info.value)
-        return out
+        return out, linv
 
     def dgemm(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, C_out=None):
         A, B = self.dev(A), self.dev(B)

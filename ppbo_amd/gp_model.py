@@ -75,7 +75,7 @@ class GPModel:
         self.skip_xstaroptimization_during_initialization = s.skip_xstaroptimization_during_initialization
         self.fit_stats = None
         # device state
-        self._dX = self._dSigma = self._dSigma_inv = None
+        self._dX = self._dSigma = self._dSigma_inv = self._dLinv = None
         self._post = None           # engine.Posterior with G (variance operator)
         self._post_mean = None      # Posterior usable for the mean only (alpha current, no G)
         self._host = {}
@@ -176,12 +176,14 @@ class GPModel:
         if (self.incremental and st is not None and st[1] == th and st[2] < APPEND_REFRESH
                 and 0 < self.N - st[0].shape[0] <= 64 and np.array_equal(self.X[:st[0].shape[0]], st[0])):
             try:
-                self._dSigma_inv = self.eng.pd_inverse_append(self._dSigma, self._dSigma_inv)
+                self._dSigma_inv, self._dLinv = self.eng.pd_inverse_append(self._dSigma, self._dSigma_inv, self._dLinv)
                 self._sinv_state = (self.X.copy(), th, st[2] + 1)
                 done = True
             except NotPositiveDefinite:
                 pass                      # Schur complement lost definiteness to rounding: full inversion below
-        if not done:
+        if not done and self.incremental:
+            self._dSigma_inv, self._dLinv = self.eng.pd_inverse_factors(self._dSigma)
+        elif not done:
             self._dSigma_inv = self.eng.pd_inverse(self._dSigma)
             self._sinv_state = (self.X.copy(), th, 0)
         self._invalidate("Sigma_inv", "Pinv")

@@ -26,15 +26,19 @@ def test_bordered_inverse_matches_full_inverse(eng, golden, name):
     n_q = N // mb
     q0 = max(1, n_q // 2)
     Xd = eng.dev(X)
-    Sinv = eng.pd_inverse(eng.gram(Xd[:q0 * mb], th, kern))
+    Sinv, Linv = eng.pd_inverse_factors(eng.gram(Xd[:q0 * mb], th, kern))
     for q in range(q0, n_q):
         Sig = eng.gram(Xd[:(q + 1) * mb], th, kern)
-        Sinv = eng.pd_inverse_append(Sig, Sinv)
-    full = eng.pd_inverse(Sig)
+        Sinv, Linv = eng.pd_inverse_append(Sig, Sinv, Linv)
+    full, Lfull = eng.pd_inverse_factors(Sig)
     Sg, A, B = Sig.cpu().numpy(), Sinv.cpu().numpy(), full.cpu().numpy()
     I = np.eye(N)
     res_app, res_full = np.abs(Sg @ A - I).max(), np.abs(Sg @ B - I).max()
+    print(f"{name}: |Sigma Sinv - I| appended {res_app:.2e} / full {res_full:.2e} after {n_q - q0} appends")
     assert res_app <= 20 * res_full + 1e-9, (res_app, res_full)
+    La, Lf = Linv.cpu().numpy(), Lfull.cpu().numpy()
+    assert np.abs(np.triu(La, 1)).max() == 0.0
+    assert np.abs(La - Lf).max() <= 1e-7 * np.abs(Lf).max()
     f = g["fMAP"]
     a_app, a_full = A @ f, B @ f
     assert np.abs(a_app - a_full).max() <= 1e-6 * np.abs(a_full).max()
@@ -48,9 +52,9 @@ def test_bordered_inverse_matches_full_inverse(eng, golden, name):
 def test_append_rejects_bad_arguments(eng):
     A = eng.dev(np.eye(8))
     with pytest.raises(RuntimeError):
-        eng.pd_inverse_append(A, eng.dev(np.eye(8)))          # nothing appended
+        eng.pd_inverse_append(A, eng.dev(np.eye(8)), eng.dev(np.eye(8)))          # nothing appended
     with pytest.raises(RuntimeError):
-        eng.pd_inverse_append(eng.dev(np.eye(200)), eng.dev(np.eye(100)))   # more than 64 rows at once
+        eng.pd_inverse_append(eng.dev(np.eye(200)), eng.dev(np.eye(100)), eng.dev(np.eye(100)))   # > 64 rows at once
 
 
 def test_append_reports_indefinite_border(eng):
@@ -58,7 +62,7 @@ def test_append_reports_indefinite_border(eng):
     A = np.eye(6)
     A[5, 5] = -1.0
     with pytest.raises(NotPositiveDefinite):
-        eng.pd_inverse_append(eng.dev(A), eng.dev(np.eye(4)))
+        eng.pd_inverse_append(eng.dev(A), eng.dev(np.eye(4)), eng.dev(np.eye(4)))
 
 
 def _replay(golden, incremental, gtol=1e-8):
