@@ -169,6 +169,9 @@ typedef struct ppbo_model {
   const double* d_lam_diag; /* [N]  Lambda_MAP diagonal   */
   const double* d_lam_off;  /* [N]  Lambda_MAP star edges */
   const double* d_G;        /* [N,N] R W, see ppbo_posterior */
+  int kstar_fp32;           /* 0: everything fp64 (the product path).  1: K* entries evaluated in fp32 from direct
+                             * differences, all accumulation fp64 -- BASELINE config 5's "fp32 tolerance" variant;
+                             * its error against the fp64 path is REPORTED (bench.py), it does not meet 1e-5 */
 } ppbo_model;
 int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
                  int score_kind, double mustar, double* d_mu, double* d_var, double* d_score,

@@ -32,7 +32,7 @@ class FitStats(C.Structure):
 class Model(C.Structure):
     _fields_ = [("kernel_id", C.c_int), ("N", C.c_int), ("D", C.c_int), ("m", C.c_int),
                 ("theta", C.c_double * 3), ("d_X", C.c_void_p), ("d_alpha", C.c_void_p),
-                ("d_lam_diag", C.c_void_p), ("d_lam_off", C.c_void_p), ("d_G", C.c_void_p)]
+                ("d_lam_diag", C.c_void_p), ("d_lam_off", C.c_void_p), ("d_G", C.c_void_p), ("kstar_fp32", C.c_int)]
 
 
 _vp, _i, _d, _i64 = C.c_void_p, C.c_int, C.c_double, C.c_int64

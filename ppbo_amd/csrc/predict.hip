@@ -35,7 +35,26 @@ constexpr int KS_RJ = 32;   // X rows staged in LDS per step
 // unrolled; every lane reads the same LDS address (broadcast), one ds_read_b128 per 2 dims.
 // KS_CPT candidates per lane share each of those reads: with the one-FMA-per-dimension form the kernel is
 // bound by the LDS pipe (a broadcast b128 read still returns 1 KB per wavefront), not by the vector ALUs.
-template <int KID, int DP>
+// fp32 kernel evaluation (F32 = true): the "fp32 tolerance" variant BASELINE config 5 names.  K* entries are
+// evaluated in single precision from direct differences (the expansion form loses 4e-5 of mu in fp32),
+// then widened; every accumulation (mu, k*'Lambda k*, the MFMA contraction) stays fp64.
+template <int KID>
+__device__ __forceinline__ float kern_term32(float dx, int d, float c0, float c1) {
+  if (KID == PPBO_KERNEL_CAMPHOR) {
+    if (d == 2) return c1 * dx * dx;
+    const float sn = sinpif(fabsf(dx));
+    return c0 * sn * sn;
+  }
+  return dx * dx;
+}
+template <int KID>
+__device__ __forceinline__ float kern_finish32(float s, float sf2, float c0) {
+  if (KID == PPBO_KERNEL_SE) return sf2 * expf(-c0 * s);
+  if (KID == PPBO_KERNEL_RQ) { const float t = 1.0f + s * c0; return sf2 / (t * t); }
+  return sf2 * expf(-s);
+}
+
+template <int KID, int DP, bool F32 = false>
 __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
     const double* __restrict__ X, int N, int D, KernParams p, const double* __restrict__ alpha,
     const double* __restrict__ lam_diag, const double* __restrict__ lam_off, int mblk,
@@ -49,14 +68,17 @@ __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
   // rounding is the rounding every entry of Sigma already carries (posterior mean / variance move by
   // <= 3e-13 / 1e-13 sigma_f^2 on the fixtures against direct differences).  The camphor kernel needs the
   // differences themselves.
-  constexpr bool EXPAND = (KID != PPBO_KERNEL_CAMPHOR);
+  constexpr bool EXPAND = (KID != PPBO_KERNEL_CAMPHOR) && !F32;
   double xc[KS_CPT][DP], nc[KS_CPT], mu[KS_CPT], tl[KS_CPT], ko[KS_CPT];
+  float xcf[KS_CPT][DP];
+  const float c0f = (float)p.c0, c1f = (float)p.c1, sf2f = (float)p.sf2;
 #pragma unroll
   for (int q = 0; q < KS_CPT; ++q) {
     nc[q] = 0.0; mu[q] = 0.0; tl[q] = 0.0; ko[q] = 0.0;
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
       double v = (d < D && c0 + q < M) ? Xc[(size_t)(c0 + q) * D + d] : 0.0;
+      if (F32) xcf[q][d] = (float)v;
       if (EXPAND) { nc[q] = fma(v, v, nc[q]); v *= -2.0; }
       xc[q][d] = v;
     }
@@ -92,9 +114,22 @@ __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
     for (int r = 0; r < rmax; ++r) {
       const double* __restrict__ xr = xs + r * DP;
       double sv[KS_CPT];
+      double kv[KS_CPT];
 #pragma unroll
       for (int q = 0; q < KS_CPT; ++q) sv[q] = 0.0;
-      if (EXPAND) {
+      if (F32) {
+        float sf[KS_CPT];
+#pragma unroll
+        for (int q = 0; q < KS_CPT; ++q) sf[q] = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+          const float x = (float)xr[d];
+#pragma unroll
+          for (int q = 0; q < KS_CPT; ++q) sf[q] += kern_term32<KID>(x - xcf[q][d], d, c0f, c1f);
+        }
+#pragma unroll
+        for (int q = 0; q < KS_CPT; ++q) kv[q] = (double)kern_finish32<KID>(sf[q], sf2f, c0f);
+      } else if (EXPAND) {
 #pragma unroll
         for (int d = 0; d < DP; ++d) {
           const double x = xr[d];
@@ -112,9 +147,10 @@ __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
           for (int q = 0; q < KS_CPT; ++q) sv[q] += kern_term<KID>(x - xc[q][d], d, p);
         }
       }
-      double kv[KS_CPT];
+      if (!F32) {
 #pragma unroll
-      for (int q = 0; q < KS_CPT; ++q) kv[q] = kern_finish<KID>(sv[q], p);
+        for (int q = 0; q < KS_CPT; ++q) kv[q] = kern_finish<KID>(sv[q], p);
+      }
       if (Kt) {
         double* dst = Kt + (size_t)(row0 + r) * ldk + c0;
         if (vec) {      // 1 GB streamed out once, read back by the next kernel
@@ -356,6 +392,17 @@ int launch_kstar(const ppbo_model* m, const KernParams& p, const double* d_Xc, i
   const int mblk = m->m + 1, n_q = (m->N + mblk - 1) / mblk;
   const double* ld = with_lam ? m->d_lam_diag : nullptr;
   const double* lo = with_lam ? m->d_lam_off : nullptr;
+#define KS_LAUNCH32(DP)                                                                                              \
+  kstar_kernel<KID, DP, true><<<grid, KS_THREADS, 0, s>>>(m->d_X, m->N, m->D, p, m->d_alpha, ld, lo, mblk, d_Xc, M, \
+                                                          Kt, ldk, mu_part, with_lam ? t_part : nullptr,            \
+                                                          q_per_split, n_q)
+  if (m->kstar_fp32) {       // the fp32-tolerance report: the BASELINE shapes get their own bucket, the rest a generic one
+    if (KID == PPBO_KERNEL_CAMPHOR || m->D <= 6) KS_LAUNCH32(6);
+    else if (m->D <= 20) KS_LAUNCH32(20);
+    else KS_LAUNCH32(64);
+    return 0;
+  }
+#undef KS_LAUNCH32
 #define KS_LAUNCH(DP)                                                                                          \
   kstar_kernel<KID, DP><<<grid, KS_THREADS, 0, s>>>(m->d_X, m->N, m->D, p, m->d_alpha, ld, lo, mblk, d_Xc, M, \
                                                     Kt, ldk, mu_part, with_lam ? t_part : nullptr,            \

@@ -91,7 +91,7 @@ class Engine:
     def _theta(theta):
         return (C.c_double * 3)(float(theta[0]), float(theta[1]), float(theta[2]))
 
-    def _model(self, post: Posterior, with_var=True):
+    def _model(self, post: Posterior, with_var=True, kstar_fp32=False):
         N, D = post.X.shape
         md = _lib.Model()
         md.kernel_id = KERNEL_IDS[post.kernel]
@@ -102,6 +102,7 @@ class Engine:
         md.d_lam_diag = post.lam_diag.data_ptr() if post.lam_diag is not None else 0
         md.d_lam_off = post.lam_off.data_ptr() if post.lam_off is not None else 0
         md.d_G = post.G.data_ptr() if (with_var and post.G is not None) else 0
+        md.kstar_fp32 = int(bool(kstar_fp32))
         return md
 
     # ---- per-kernel event timing ---------------------------------------------
@@ -263,11 +264,11 @@ class Engine:
 
     # ---- prediction ---------------------------------------------------------------
     def predict(self, post: Posterior, Xc, score=SCORE_MEAN, mustar=0.0, want_mu=True, want_var=True,
-                want_score=False, want_best=True):
+                want_score=False, want_best=True, kstar_fp32=False):
         Xc = self.dev(Xc)
         M = Xc.shape[0]
         with_var = want_var or score != SCORE_MEAN
-        md = self._model(post, with_var)
+        md = self._model(post, with_var, kstar_fp32)
         mu = self.empty(M) if want_mu else None
         var = self.empty(M) if (want_var and with_var) else None
         sc = self.empty(M) if want_score else None
