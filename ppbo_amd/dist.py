@@ -52,3 +52,27 @@ def sharded_search(engine, post, Xc_shard, shard_offset: int, score, mustar=0.0,
                          want_score=False, want_best=True)
     gidx = out["best_idx"] + shard_offset if out["best_idx"] >= 0 else -1
     return allgather_argmax(out["best_val"], gidx, device=engine.device, group=group)
+
+
+def rank_world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def allgather_strided(local_vals, n_total: int, device=None, group=None):
+    """Rank r holds the values of items r, r + world, r + 2 world, ... (in that order); every rank gets all
+    n_total values in item order from ONE all-gather of equally padded float64 records."""
+    rank, world = rank_world(group)
+    if world == 1:
+        assert len(local_vals) == n_total
+        return [float(v) for v in local_vals]
+    per = (n_total + world - 1) // world
+    dev = device if device is not None else torch.device("cpu")
+    rec = torch.full((per,), float("nan"), dtype=torch.float64)
+    rec[:len(local_vals)] = torch.as_tensor(list(local_vals), dtype=torch.float64)
+    rec = rec.to(dev)
+    out = torch.empty(per * world, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, rec, group=group)
+    out = out.cpu().view(world, per)
+    return [float(out[k % world, k // world]) for k in range(n_total)]

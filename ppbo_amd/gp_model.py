@@ -233,27 +233,84 @@ class GPModel:
             out = ndtr(delta / np.sqrt(2.0)).sum(axis=1)
         return np.repeat(out, mb) if over_all_indices else out
 
+    # ------------------------------------------------------------------ concurrent fits
+    def _side_engines(self, n):
+        """n extra (Engine, stream) pairs on this model's GPU.  One f_MAP fit is a latency-bound chain of small
+        launches that leaves most of the chip idle, so independent fits (evidence at different theta, the random
+        restarts of the last iteration) run concurrently: one ppbo_ctx (private workspaces) and one HIP stream per
+        host thread; ctypes releases the GIL inside every library call."""
+        import torch
+        from .engine import Engine
+        pool = self.__dict__.setdefault("_side_pool", [])
+        while len(pool) < n:
+            pool.append((Engine(self.eng.device.index), torch.cuda.Stream(device=self.eng.device)))
+        return pool[:n]
+
+    def _run_concurrently(self, jobs, workers):
+        """jobs: callables taking an Engine; returns their results in order.  workers <= 1: run on self.eng."""
+        import queue
+        import threading
+        import torch
+        if workers <= 1 or len(jobs) <= 1:
+            return [job(self.eng) for job in jobs]
+        side = self._side_engines(min(workers, len(jobs)))
+        main = torch.cuda.current_stream(self.eng.device)
+        todo = queue.Queue()
+        for k, job in enumerate(jobs):
+            todo.put((k, job))
+        out, errs = [None] * len(jobs), []
+
+        def worker(eng, stream):
+            stream.wait_stream(main)                     # inputs were produced on the caller's stream
+            with torch.cuda.stream(stream):
+                while True:
+                    try:
+                        k, job = todo.get_nowait()
+                    except queue.Empty:
+                        break
+                    try:
+                        out[k] = job(eng)
+                    except Exception as e:           # noqa: BLE001  (re-raised in the caller's thread)
+                        errs.append(e)
+                stream.synchronize()
+
+        threads = [threading.Thread(target=worker, args=pair) for pair in side]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        if errs:
+            raise errs[0]
+        return out
+
+    @staticmethod
+    def _default_workers(N):
+        return 8 if N <= 1024 else (4 if N <= 2048 else 2)
+
     # ------------------------------------------------------------------ evidence / hyper-parameters
+    def _evidence_core(self, eng, theta, f0):
+        """One Laplace evidence on `eng` from the start vector f0 (device); returns (value incl. log-prior, log-evidence)."""
+        import scipy.stats
+        Sig = eng.gram(self._dX, theta, self.kernel.__name__, self.COVARIANCE_SHRINKAGE)
+        Sinv = eng.pd_inverse(Sig)
+        fm, st = eng.fit_fmap(Sinv, f0, self.m, theta[0], gtol=1e-4, maxiter=500)
+        _, _, ld, lo = eng.laplace_terms(fm, self.m, theta[0])
+        sgn, logdet, _ = eng.laplace_logdet(Sig, ld, lo, self.m)
+        log_evidence = st["T"] - 0.5 * sgn * logdet
+        lp = (np.log(scipy.stats.lognorm.pdf(theta[0], s=1, scale=np.exp(1)))
+              + np.log(scipy.stats.lognorm.pdf(theta[1], s=0.5, scale=np.exp(-1.4)))
+              + np.log(scipy.stats.lognorm.pdf(theta[2], s=0.5, scale=np.exp(1.7))))
+        return log_evidence + lp, log_evidence
+
     def evidence(self, theta, f_initial):
         """Laplace log-marginal likelihood + log-prior (gp_model.py:278-319) on the device.
         As in the reference, f_initial is IGNORED and redrawn from N(0, self.Sigma) (:294), the matrix is
         I + Sigma_theta*Lambda_MAP (plus sign, :302) and the determinant term is the sum of sign*logdet over the
         LU factors (:307-310), i.e. sign(prod diag U) * sum log|diag U| with LAPACK's pivoting."""
-        import scipy.stats
         theta = [float(t) for t in theta]
         if self.verbose:
             print("---------- Iter results ----------------")
-        Sig = self.eng.gram(self._dX, theta, self.kernel.__name__, self.COVARIANCE_SHRINKAGE)
-        Sinv = self.eng.pd_inverse(Sig)
-        f0 = self._draw_prior()
-        fm, st = self.eng.fit_fmap(Sinv, f0, self.m, theta[0], gtol=1e-4, maxiter=500)
-        _, _, ld, lo = self.eng.laplace_terms(fm, self.m, theta[0])
-        sgn, logdet, _ = self.eng.laplace_logdet(Sig, ld, lo, self.m)
-        log_evidence = st["T"] - 0.5 * sgn * logdet
-        lp = (np.log(scipy.stats.lognorm.pdf(theta[0], s=1, scale=np.exp(1)))
-              + np.log(scipy.stats.lognorm.pdf(theta[1], s=0.5, scale=np.exp(-1.4)))
-              + np.log(scipy.stats.lognorm.pdf(theta[2], s=0.5, scale=np.exp(1.7))))
-        value = log_evidence + lp
+        value, log_evidence = self._evidence_core(self.eng, theta, self._draw_prior())
         if self.verbose:
             print("(scaled) Log-evidence: " + str(log_evidence))
             print("Hyper-parameters: " + str(theta))
@@ -265,25 +322,45 @@ class GPModel:
             print("(scaled) Log-evidence + Log-prior: " + str(value))
         return float(value)
 
-    def optimize_theta(self):
+    def evidence_batch(self, thetas, workers=None):
+        """evidence() at many thetas: the start vectors are drawn first, in order, from the global stream (so the
+        values equal those of sequential evidence() calls), then the independent fits run concurrently on this GPU;
+        under torch.distributed (one process per GPU) rank r takes thetas[r::world] and ONE all-gather returns all
+        values to every rank.  NaN / inf -> -500 as in the reference (gp_model.py:314-316)."""
+        from . import dist as _dist
+        thetas = [[float(t) for t in th] for th in thetas]
+        f0s = [self._draw_prior() for _ in thetas]
+        rank, world = _dist.rank_world()
+        mine = list(range(rank, len(thetas), world))
+        workers = self._default_workers(self.N) if workers is None else workers
+        jobs = [(lambda eng, k=k: self._evidence_core(eng, thetas[k], f0s[k])[0]) for k in mine]
+        vals = self._run_concurrently(jobs, workers)
+        vals = [(-500.0 if (v != v or not np.isfinite(v)) else float(v)) for v in vals]
+        return _dist.allgather_strided(vals, len(thetas), device=self.eng.device)
+
+    def optimize_theta(self, workers=None):
         """Evidence maximisation over (l, sigma_f) with sigma fixed to 1 (gp_model.py:391-413).  The reference
         drives GPyOpt's Bayesian optimisation (20 initial + 40 iterations = 60 evidence fits); GPyOpt is replaced
-        by the same budget of device evidence fits: 20 uniform draws over the reference's box, then 40 shrinking
-        Gaussian perturbations of the incumbent."""
+        by the same budget of device evidence fits: 20 uniform draws over the reference's box (one concurrent
+        batch), then 4 batches of 10 shrinking Gaussian perturbations of the incumbent.  The search TRAJECTORY is
+        unpinned (GPyOpt==1.2.6 absent); the objective is the pinned evidence()."""
         if self.verbose:
             print("Hyperparameter optimization begins...")
         start = time.time()
         lo, hi = np.array([0.01, 0.1]), np.array([2.0, 15.0])
         best_v, best_t = -np.inf, None
-        for k in range(60):
-            if k < 20 or best_t is None:
-                cand = lo + np.random.uniform(size=2) * (hi - lo)
+        self.theta_search_log = []
+        for rnd in range(5):
+            if rnd == 0:
+                cands = lo + np.random.uniform(size=(20, 2)) * (hi - lo)
             else:
-                width = 0.25 * (hi - lo) * (0.93 ** (k - 20))
-                cand = np.clip(best_t + width * np.random.standard_normal(2), lo, hi)
-            v = self.evidence([1.0, cand[0], cand[1]], self.fMAP)
-            if v > best_v:
-                best_v, best_t = v, cand
+                width = 0.25 * (hi - lo) * (0.5 ** (rnd - 1))
+                cands = np.clip(best_t + width * np.random.standard_normal((10, 2)), lo, hi)
+            vals = self.evidence_batch([[1.0, c[0], c[1]] for c in cands], workers=workers)
+            for c, v in zip(cands, vals):
+                self.theta_search_log.append((float(c[0]), float(c[1]), float(v)))
+                if v > best_v:
+                    best_v, best_t = v, c
         if self.verbose:
             print("Optimization of hyperparameters took " + str(time.time() - start) + " seconds.")
         self.theta = [1.0, float(best_t[0]), float(best_t[1])]
@@ -294,8 +371,12 @@ class GPModel:
     def _draw_prior(self):
         """f ~ N(0, Sigma) for the random start (gp_model.py:374,381): L z with the device Cholesky
         factor and z from the global NumPy stream (the reference uses np.random.multivariate_normal)."""
-        L = self.eng.potrf_(self._dSigma.clone())
-        return self.eng.dgemv(L, np.random.standard_normal(self.N), lower=True)
+        key = (self._dSigma.data_ptr(), getattr(self._dSigma, "_version", 0))
+        cache = self.__dict__.get("_prior_chol")
+        if cache is None or cache[0] != key:
+            cache = (key, self.eng.potrf_(self._dSigma.clone()), self._dSigma)     # keeps Sigma alive: the pointer stays unique
+            self._prior_chol = cache
+        return self.eng.dgemv(cache[1], np.random.standard_normal(self.N), lower=True)
 
     def update_fMAP(self, random_initial_vector=None, fmap_finding_trials=None, approx_optimization=False):
         trials = self.fMAP_finding_trials if fmap_finding_trials is None else fmap_finding_trials
@@ -311,8 +392,8 @@ class GPModel:
                 and random_initial_vector is None and fmap_finding_trials is None)
         if warm:
             rnd, trials = False, 1
+        starts = []
         for _ in range(trials):
-            t_trial = time.time()
             if self.fMAP is None or rnd or len(self.fMAP) > self.N:
                 f0 = self._draw_prior()
             elif len(self.fMAP) < self.N:
@@ -327,9 +408,18 @@ class GPModel:
                 f0 = np.concatenate([self.fMAP, pad])
             else:
                 f0 = self.fMAP
-            fm, st = self.eng.fit_fmap(self._dSigma_inv, f0, self.m, self.theta[0], gtol=gtol)
+            starts.append(self.eng.dev(f0))
+        # independent restarts (the reference's 10 on the last iteration, gp_model.py:96-97) run concurrently
+        t_fit = time.time()
+        jobs = [(lambda eng, f0=f0: eng.fit_fmap(self._dSigma_inv, f0, self.m, self.theta[0], gtol=gtol)) for f0 in starts]
+        results = self._run_concurrently(jobs, self._default_workers(self.N) if trials > 1 else 1)
+        t_fit = (time.time() - t_fit) / max(trials, 1)
+        for fm, st in results:
+            if trials > 1:               # produced on a side stream, consumed on the caller's from here on
+                import torch
+                fm.record_stream(torch.cuda.current_stream(self.eng.device))
             self.fit_log.append(dict(N=self.N, iterations=st["iterations"], n_cholesky=st["n_cholesky"],
-                                     converged=st["converged"], warm=bool(warm), seconds=time.time() - t_trial))
+                                     converged=st["converged"], warm=bool(warm), seconds=t_fit))
             if not st["converged"] and not approx_optimization and st["gradnorm"] > 1e3 * gtol:
                 # the trust region stalled far from stationarity (no descent predicted / radius collapsed): the
                 # reference would hand back SciPy's last iterate; one fresh start from the prior is cheap here

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ppbo_amd.dist import allgather_argmax, combine_best, shard_bounds
+from ppbo_amd.dist import allgather_argmax, allgather_strided, combine_best, shard_bounds
 
 
 def _free_port():
@@ -74,3 +74,33 @@ def test_combine_best_semantics():
     assert (v, i) == (3.0, 2)
     v, i = combine_best(torch.tensor([float("nan")]), torch.tensor([-1]))
     assert i == -1
+
+
+def _worker_strided(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = [100.0 + k for k in range(rank, n_total, world)]        # item k is evaluated by rank k % world
+    q.put((rank, allgather_strided(mine, n_total)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [1, 7, 20, 60])
+def test_theta_slices_are_gathered_in_item_order(n_total):
+    """optimize_theta under --gpus N: rank r evaluates thetas[r::world]; one all-gather returns all 60 values."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_strided, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, vals in res:
+        assert vals == [100.0 + k for k in range(n_total)]
+
+
+def test_strided_gather_single_process():
+    assert allgather_strided([1.0, 2.0, 3.0], 3) == [1.0, 2.0, 3.0]
