@@ -125,6 +125,7 @@ typedef struct ppbo_fit_opts {
   double gtol;    /* reference default 1e-4 (SciPy); 100 during initialisation (src/gp_model.py:365-366) */
   int maxiter;    /* <=0: 200*N like SciPy */
   int verbose;
+  double initial_radius;   /* first trust radius; <= 0: SciPy's default 1.0 (what the reference runs with) */
 } ppbo_fit_opts;
 typedef struct ppbo_fit_stats {
   int iterations;   /* outer trust-region iterations */

@@ -21,7 +21,7 @@ SCORE_MEAN, SCORE_POINTWISE_EI, SCORE_VARIANCE = 0, 1, 2
 
 
 class FitOpts(C.Structure):
-    _fields_ = [("gtol", C.c_double), ("maxiter", C.c_int), ("verbose", C.c_int)]
+    _fields_ = [("gtol", C.c_double), ("maxiter", C.c_int), ("verbose", C.c_int), ("initial_radius", C.c_double)]
 
 
 class FitStats(C.Structure):

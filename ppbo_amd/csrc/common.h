@@ -32,7 +32,7 @@ struct ppbo_ctx {
   // kernels whose dynamic-LDS limit has been raised on THIS ctx's device (hipFuncSetAttribute is per device)
   std::vector<const void*> lds_raised;
   // tuning knobs, read from the environment once per ctx (ppbo_ctx_create); defaults = measured best
-  int qf_variant = 2, qf_order = 258, potrf_gen = 3;
+  int qf_variant = 2, qf_order = 258, potrf_gen = 3, rff_nt = 0, gram_variant = 0;
 };
 
 // Every extern "C" entry runs on its ctx's device and leaves the caller's current device as it found it.
@@ -122,6 +122,14 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_through2(double* p, double x, double y) {
   const double2_t v = {x, y};
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// the value lane ^ 1 holds (DPP quad_perm [1,0,3,2]): two 32-bit moves, no LDS
+__device__ __forceinline__ double lane_xor1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
 }
 
 // 64-lane wavefront reductions (gfx950: wave = 64)

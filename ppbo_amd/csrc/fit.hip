@@ -383,12 +383,12 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
   PPBO_HIP_CHECK(ctx, hipMemcpyAsync(pt[cur].f, d_f_init, vbytes, hipMemcpyDeviceToDevice, s));
   if (int rc = eval_point(W, pt[cur])) return rc;
 
-  double radius = 1.0;
+  double radius = (opts && opts->initial_radius > 0.0) ? opts->initial_radius : 1.0;
   const double rmax = 1000.0, eta = 0.15, k_easy = 0.1, k_hard = 0.2;
   std::vector<double> host_p(N), host_z(N), host_lz(N), host_g(N);
   bool host_g_valid = false;
   double lam_lb_prev = 0.0;
-  double prev_lam = 0.0, prev_radius = 1.0;
+  double prev_lam = 0.0, prev_radius = radius;
   bool prev_boundary = false, prev_failed = false;
   bool shrink = false, h_changed = true;
   double st_mindiag = 0, st_gmax = 0, st_gmin = 0, st_fro = 0, st_inf = 0;

@@ -237,7 +237,7 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
 constexpr int PANEL_ROUNDS = 6;
 
 __device__ __forceinline__ void potrf_update_part(double* __restrict__ A, int lda, int N, int k0, int nP, int ntS,
-                                                  double* __restrict__ plds, int rank, int r0) {
+                                                  double* __restrict__ plds, int rank, int r0, int info_in) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double* Pi = plds;
@@ -273,6 +273,8 @@ __device__ __forceinline__ void potrf_update_part(double* __restrict__ A, int ld
   int rnd = r0;
   int cur = tile_of(rnd);
   if (cur < total) fetch(cur);
+  if (info_in != 0) return;      // a failed factorization: checked only now, so that the flag's round trip does not
+                                 // delay the first tile's loads (it used to cost every launch ~1 us up front)
   for (; cur < total;) {
     const int nxt = tile_of(rnd + 1);
     const bool v_cur = valid, diag_cur = (ti == tj);
@@ -555,18 +557,17 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
                                                          int nP, int ntS, double* __restrict__ diag_out,
                                                          int* __restrict__ info, double* __restrict__ fail_pivot) {
   extern __shared__ __attribute__((aligned(16))) double plds[];
-  const int info_in = *info;
-  if (info_in != 0) return;
+  const int info_in = *info;     // consumed after the first loads are in flight (both parts)
   const int nSW = gridDim.x - nP;
   if ((int)blockIdx.x >= nP) {
-    potrf_update_part(A, lda, N, k0, nP, ntS, plds, blockIdx.x - nP, 0);
+    potrf_update_part(A, lda, N, k0, nP, ntS, plds, blockIdx.x - nP, 0, info_in);
     return;
   }
   if (!potrf_panel_part(A, lda, N, k0, has_prev, diag_out, info, fail_pivot, plds, info_in)) return;
   // the panel is done; help with the trailing update (the tile lists of the rounds >= PANEL_ROUNDS)
   if (ntS == 0 || PANEL_ROUNDS * nSW >= (ntS + 1) * ((ntS + 1) / 2)) return;
   __syncthreads();
-  potrf_update_part(A, lda, N, k0, nP, ntS, plds, nSW + blockIdx.x, PANEL_ROUNDS);
+  potrf_update_part(A, lda, N, k0, nP, ntS, plds, nSW + blockIdx.x, PANEL_ROUNDS, 0);
 }
 
 // After a failed factorization of H + lam I at (0-based) column kf with pivot d <= 0, Conn/Gould/Toint's

@@ -25,57 +25,93 @@ constexpr double INV_SQRT_4PI = 0.28209479177387814347;
   }
 }
 
-// cos(x) for |x| < 1.6e6 as -(-1)^k sin(r), |x| = (2k+1) pi/2 + r with |r| <= pi/2: Cody-Waite reduction by
-// four 33-bit pieces of pi/2 (the odd multiplier is exact), then ONE odd minimax polynomial of degree 19
-// (fit error 3e-22, tools/expfit.py has the recipe) -- about 24 fp64 instructions and <= 1 ulp, against ~40 for
-// the usual reduction to pi/4 that evaluates a sine AND a cosine kernel and selects.  Larger arguments take
-// the library path.  The RFF phases w.x + b are O(sqrt(D)/l) (tens), far inside the fast range.
-__device__ __forceinline__ double rff_cos(double x) {
+// cos(x) for |x| < 1.6e6 as (-1)^k sin(r), |x| = (2k - 1) pi/2 + r with |r| <= pi/2, k = rint(|x|/pi + 1/2):
+// Cody-Waite reduction by three 33-bit pieces of pi/2 (the odd multiplier 2k-1 < 2^21 is exact against each), then
+// ONE odd minimax polynomial sin(r) = r P(r^2), nine coefficients (fit error 2e-19, <= 1 ulp in double; the recipe
+// is tools/expfit.py sin_fit) -- 17 fp64 instructions + 3 integer ones for the sign (the parity of k moved into
+// the sign bit), against ~40 for a library cosine that reduces to pi/4 and evaluates a sine AND a cosine kernel.
+// The RFF phases w.x + b are O(sqrt(D)/l) (tens), far inside the fast range; larger arguments take the library
+// path behind a wave-uniform branch (rff_cos_slow is out of line: one copy per kernel, not one per element).
+constexpr double RFF_COS_FAST_RANGE = 1.6e6;
+__device__ __attribute__((noinline)) double rff_cos_slow(double x) { return cos(x); }
+
+struct RffPoly {   // c[k] = amplitude * (coefficient of r^(2k+1)), prepared on the host: the feature scale rides along
+  double c[9];
+};
+static inline RffPoly make_rff_poly(double amplitude) {
+  static const double s[9] = {0x1.0000000000000p+0,  -0x1.5555555555555p-3, 0x1.11111111110bcp-7,
+                              -0x1.a01a01a0147d9p-13, 0x1.71de3a528c5e5p-19, -0x1.ae6454d01e7a1p-26,
+                              0x1.6123ccc2fc0b0p-33,  -0x1.ae4398eddfa1fp-41, 0x1.8837bd66b70acp-49};
+  RffPoly p;
+  for (int k = 0; k < 9; ++k) p.c[k] = amplitude * s[k];
+  return p;
+}
+
+// amplitude * cos(x); branch-free, valid for |x| < RFF_COS_FAST_RANGE: independent evaluations interleave
+__device__ __forceinline__ double rff_cos_fast(double x, const RffPoly& P) {
   const double ax = fabs(x);
-  if (!(ax < 1.6e6)) return cos(x);
-  const double kf = rint(fma(ax, 3.18309886183790671538e-01, -0.5));
-  const double n = fma(2.0, kf, 1.0);
+  const double kf = rint(fma(ax, 3.18309886183790671538e-01, 0.5));
+  const double n = fma(2.0, kf, -1.0);
   double r = fma(-n, 1.57079632673412561417e+00, ax);
   r = fma(-n, 6.07710050630396597660e-11, r);
   r = fma(-n, 2.02226624871116645580e-21, r);
-  r = fma(-n, 8.47842766036889956997e-32, r);
   const double z = r * r;
-  double q = -0x1.26805104f0fb2p-57;
-  q = fma(q, z, 0x1.94fe99353aaa5p-49);
-  q = fma(q, z, -0x1.ae7eb995a1519p-41);
-  q = fma(q, z, 0x1.61246051b86e7p-33);
-  q = fma(q, z, -0x1.ae64567d5b22ap-26);
-  q = fma(q, z, 0x1.71de3a5569d7bp-19);
-  q = fma(q, z, -0x1.a01a01a019fdbp-13);
-  q = fma(q, z, 0x1.1111111111111p-7);
-  q = fma(q, z, -0x1.5555555555555p-3);
-  const double sn = fma(r * z, q, r);
-  return (((int)kf) & 1) ? sn : -sn;
+  double q = P.c[8];
+  q = fma(q, z, P.c[7]);
+  q = fma(q, z, P.c[6]);
+  q = fma(q, z, P.c[5]);
+  q = fma(q, z, P.c[4]);
+  q = fma(q, z, P.c[3]);
+  q = fma(q, z, P.c[2]);
+  q = fma(q, z, P.c[1]);
+  q = fma(q, z, P.c[0]);
+  const double sn = r * q;
+  // (-1)^k: the parity of k goes straight into the sign bit
+  const int flip = ((int)kf) << 31;
+  return __hiloint2double(__double2hiint(sn) ^ flip, __double2loint(sn));
 }
 
-// Phi tile [64 features x 64 points] with the phase w_f.x_n on the fp64 matrix cores (depth DP, compile
-// time) and b_f added in the epilogue.  Eight wavefronts per tile: wave = (16 feature rows, 32 points), so a
-// CU holding two tiles keeps four wavefronts per SIMD busy and the first (write-through) stores leave after
-// half a strip's arithmetic; every store instruction writes four full 128-byte lines.
-template <int DP>
+__device__ __forceinline__ double rff_cos(double x, const RffPoly& P) {
+  if (!(fabs(x) < RFF_COS_FAST_RANGE)) return P.c[0] * rff_cos_slow(x);
+  return rff_cos_fast(x, P);
+}
+
+// Phi strip [64 features x NT*64 points] per workgroup.  The phase w_f.x_n + b_f comes off the fp64 matrix cores
+// (depth DP, compile time; b_f is the accumulator's initial value), the epilogue is the cosine above.
+// Eight wavefronts: wave = (16 feature rows, 32 points of every 64-point tile).
+// What the time is made of at C3 (F = 4096, N = 2048, 67 MB; tools/dev/rff_dev.hip drops one phase at a time):
+// the write-only floor of the chip is 10.3 us, the arithmetic alone 14.7 us (fp64 MFMA and fp64 VALU do not
+// overlap), and -- the expensive surprise -- every store INSTRUCTION costs issue time that does not overlap
+// either: with one 8-byte store per element the kernel took 20.7 us even when all stores hit one cached
+// megabyte.  Hence WIDE: lane pairs trade one value (DPP) so that each lane owns two adjacent columns of one
+// row and stores 16 bytes (half the store instructions; 20.7 -> 16.9 us), and NT = 4: one round of resident
+// workgroups whose operand staging is paid once.
+template <int DP, int NT, bool WIDE>
 __global__ __launch_bounds__(512) void rff_project_kernel(const double* __restrict__ X, int N, int D,
                                                           const double* __restrict__ W, int F,
-                                                          const double* __restrict__ b, double scale,
+                                                          const double* __restrict__ b, RffPoly P,
                                                           double* __restrict__ Phi) {
   constexpr int LD = DP + 2, Q = DP / 4;
   __shared__ __attribute__((aligned(16))) double Wa[TS * LD];
-  __shared__ __attribute__((aligned(16))) double Xb[TS * LD];
-  const int f0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
+  __shared__ __attribute__((aligned(16))) double Xb[NT * TS * LD];
+  const int f0 = blockIdx.y * TS, n0 = blockIdx.x * (TS * NT);
   {
-    // threads 0-255 stage the feature panel, 256-511 the point panel; 4 lanes per row
-    const int half = threadIdx.x >> 8, r = (threadIdx.x & 255) >> 2, part = threadIdx.x & 3;
-    const double* src = half ? X : W;
-    double* dst = half ? Xb : Wa;
-    const int g = (half ? n0 : f0) + r, lim = half ? N : F;
+    // 4 lanes per row; rows 0-63 are the feature panel, the rest the point strip
+    const int part = threadIdx.x & 3;
 #pragma unroll
-    for (int k = 0; k < Q; ++k) {
-      const int d = part * Q + k;
-      dst[r * LD + d] = (d < D && g < lim) ? src[(size_t)g * D + d] : 0.0;
+    for (int p = 0; p < (NT + 2) / 2; ++p) {
+      const int row = p * 128 + (threadIdx.x >> 2);
+      if (row >= (NT + 1) * TS) break;
+      const bool isw = row < TS;
+      const double* src = isw ? W : X;
+      double* dst = isw ? Wa : Xb;
+      const int r = isw ? row : row - TS;
+      const int g = (isw ? f0 : n0) + r, lim = isw ? F : N;
+#pragma unroll
+      for (int k = 0; k < Q; ++k) {
+        const int d = part * Q + k;
+        dst[r * LD + d] = (d < D && g < lim) ? src[(size_t)g * D + d] : 0.0;
+      }
     }
   }
   __syncthreads();
@@ -90,17 +126,44 @@ __global__ __launch_bounds__(512) void rff_project_kernel(const double* __restri
     bv[r] = (f < F) ? b[f] : 0.0;
   }
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj) {
-    const int j = 2 * jh + jj;
-    double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int kk = 0; kk < Q; ++kk)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], Xb[(j * 16 + lr) * LD + kk * 4 + lk], acc, 0, 0, 0);
-    const int n = n0 + j * 16 + lr;
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 4 * t + 2 * jh + jj;
+      double4_t acc = double4_t{bv[0], bv[1], bv[2], bv[3]};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = f0 + w * 16 + lk + 4 * r;
-      if (f < F && n < N) store_through(Phi + (size_t)f * N + n, scale * rff_cos(acc[r] + bv[r]));
+      for (int kk = 0; kk < Q; ++kk)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], Xb[(j * 16 + lr) * LD + kk * 4 + lk], acc, 0, 0, 0);
+      double cv[4];
+      bool big = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) big |= !(fabs(acc[r]) < RFF_COS_FAST_RANGE);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv[r] = rff_cos_fast(acc[r], P);      // four independent chains, no branches
+      if (__builtin_amdgcn_ballot_w64(big)) {                            // never taken for RFF phases
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (!(fabs(acc[r]) < RFF_COS_FAST_RANGE)) cv[r] = P.c[0] * rff_cos_slow(acc[r]);
+      }
+      if (WIDE) {
+        // even lanes keep rows lk + {0, 8}, odd lanes rows lk + {4, 12}; each stores its two adjacent columns
+        const bool odd = lane & 1;
+        const int nb = n0 + j * 16 + (lr & ~1);
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+          const double got = lane_xor1(odd ? cv[2 * rp] : cv[2 * rp + 1]);
+          const double x0 = odd ? got : cv[2 * rp], x1 = odd ? cv[2 * rp + 1] : got;
+          const int f = f0 + w * 16 + lk + 4 * (2 * rp + (odd ? 1 : 0));
+          if (f < F && nb < N) store_through2(Phi + (size_t)f * N + nb, x0, x1);      // N is even here
+        }
+      } else {
+        const int n = n0 + j * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = f0 + w * 16 + lk + 4 * r;
+          if (f < F && n < N) store_through(Phi + (size_t)f * N + n, cv[r]);
+        }
+      }
     }
   }
 }
@@ -112,7 +175,7 @@ template <int DP>
 __global__ __launch_bounds__(RS_THREADS) void rff_score_kernel(const double* __restrict__ Xc, int M, int D,
                                                                const double* __restrict__ W, int F,
                                                                const double* __restrict__ b,
-                                                               const double* __restrict__ omega, double scale,
+                                                               const double* __restrict__ omega, RffPoly P,
                                                                int f_per_split, double* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) double ws[RS_RF * DP];
   __shared__ double s_b[RS_RF], s_om[RS_RF];
@@ -151,12 +214,17 @@ __global__ __launch_bounds__(RS_THREADS) void rff_score_kernel(const double* __r
         s1 += w * xb[d];
       }
       const double om = s_om[r];
-      a0 += om * rff_cos(s0);
-      a1 += om * rff_cos(s1);
+      double v0 = rff_cos_fast(s0, P), v1 = rff_cos_fast(s1, P);       // amplitude included
+      if (__builtin_amdgcn_ballot_w64(!(fabs(s0) < RFF_COS_FAST_RANGE) || !(fabs(s1) < RFF_COS_FAST_RANGE))) {
+        if (!(fabs(s0) < RFF_COS_FAST_RANGE)) v0 = P.c[0] * rff_cos_slow(s0);
+        if (!(fabs(s1) < RFF_COS_FAST_RANGE)) v1 = P.c[0] * rff_cos_slow(s1);
+      }
+      a0 += om * v0;
+      a1 += om * v1;
     }
   }
-  if (c0 < M) part[(size_t)blockIdx.y * M + c0] = scale * a0;
-  if (c0 + 1 < M) part[(size_t)blockIdx.y * M + c0 + 1] = scale * a1;
+  if (c0 < M) part[(size_t)blockIdx.y * M + c0] = a0;
+  if (c0 + 1 < M) part[(size_t)blockIdx.y * M + c0 + 1] = a1;
 }
 
 // partial[split][n] = sum_{f in split} Phi[f][n] omega[f]
@@ -258,10 +326,26 @@ int ppbo_rff_project(ppbo_ctx* ctx, const double* d_X, int N, int D, const doubl
   PPBO_REQUIRE(ctx, N > 0 && D > 0 && D <= 256 && F > 0, "sizes");
   const double scale = std::sqrt(2.0 * sigma_f * sigma_f / (double)F);
   PPBO_REQUIRE(ctx, D <= 64, "D<=64");
-  dim3 grid((N + TS - 1) / TS, (F + TS - 1) / TS);
+  // strip length NT: one round of resident workgroups whenever the problem is large enough for it
+  const long long tiles = (long long)((N + TS - 1) / TS) * ((F + TS - 1) / TS);
+  int nt = ctx->rff_nt > 0 ? ctx->rff_nt : (tiles >= 2048 ? 4 : (tiles >= 1024 ? 2 : 1));
+  if (nt != 1 && nt != 2 && nt != 4) nt = 1;
+  const RffPoly P = make_rff_poly(scale);
+  const bool wide = (N % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_Phi) & 15) == 0);   // 16-byte row-pair stores
+  dim3 grid((N + TS * nt - 1) / (TS * nt), (F + TS - 1) / TS);
   hipStream_t s = (hipStream_t)stream;
   PpboProfScope pf(ctx, ppbo_ctx::PF_RFF_PROJECT, s);
-#define RP_LAUNCH(DPV) rff_project_kernel<DPV><<<grid, 512, 0, s>>>(d_X, N, D, d_W, F, d_b, scale, d_Phi)
+#define RP_GO(DPV, NTV)                                                                                            \
+  do {                                                                                                             \
+    if (wide) rff_project_kernel<DPV, NTV, true><<<grid, 512, 0, s>>>(d_X, N, D, d_W, F, d_b, P, d_Phi);           \
+    else rff_project_kernel<DPV, NTV, false><<<grid, 512, 0, s>>>(d_X, N, D, d_W, F, d_b, P, d_Phi);               \
+  } while (0)
+#define RP_LAUNCH(DPV)            \
+  do {                            \
+    if (nt == 4) RP_GO(DPV, 4);   \
+    else if (nt == 2) RP_GO(DPV, 2); \
+    else RP_GO(DPV, 1);           \
+  } while (0)
   if (D <= 4) RP_LAUNCH(4);
   else if (D <= 8) RP_LAUNCH(8);
   else if (D <= 12) RP_LAUNCH(12);
@@ -269,9 +353,13 @@ int ppbo_rff_project(ppbo_ctx* ctx, const double* d_X, int N, int D, const doubl
   else if (D <= 20) RP_LAUNCH(20);
   else if (D <= 24) RP_LAUNCH(24);
   else if (D <= 32) RP_LAUNCH(32);
-  else if (D <= 48) RP_LAUNCH(48);
-  else RP_LAUNCH(64);
+  else {   // deep panels: one 64-point tile per workgroup (the strip would not leave room for 4 workgroups per CU)
+    grid = dim3((N + TS - 1) / TS, (F + TS - 1) / TS);
+    if (D <= 48) RP_GO(48, 1);
+    else RP_GO(64, 1);
+  }
 #undef RP_LAUNCH
+#undef RP_GO
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
@@ -308,7 +396,7 @@ int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const do
     dim3 grid((Mc + RS_THREADS * 2 - 1) / (RS_THREADS * 2), n_split);
     PpboProfScope pf(ctx, ppbo_ctx::PF_RFF_SCORE, s);
 #define RS_LAUNCH(DP) \
-  rff_score_kernel<DP><<<grid, RS_THREADS, 0, s>>>(xc, Mc, D, d_W, F, d_b, d_omega, scale, f_per_split, part)
+  rff_score_kernel<DP><<<grid, RS_THREADS, 0, s>>>(xc, Mc, D, d_W, F, d_b, d_omega, make_rff_poly(scale), f_per_split, part)
     if (D <= 4) RS_LAUNCH(4);
     else if (D <= 6) RS_LAUNCH(6);
     else if (D <= 8) RS_LAUNCH(8);

@@ -236,11 +236,11 @@ class Engine:
         self._check(rc, "ppbo_T_and_grad")
         return T.value, grad
 
-    def fit_fmap(self, Sigma_inv, f_init, m, sigma, gtol=1e-4, maxiter=0, verbose=False):
+    def fit_fmap(self, Sigma_inv, f_init, m, sigma, gtol=1e-4, maxiter=0, verbose=False, initial_radius=0.0):
         f0 = self.dev(f_init).reshape(-1)
         N = f0.numel()
         out = self.empty(N)
-        opts = _lib.FitOpts(float(gtol), int(maxiter), int(verbose))
+        opts = _lib.FitOpts(float(gtol), int(maxiter), int(verbose), float(initial_radius))
         st = _lib.FitStats()
         rc = self.lib.ppbo_fit_fmap(self.ctx, _ptr(Sigma_inv), N, m, float(sigma), _ptr(f0), C.byref(opts), _ptr(out),
                                     C.byref(st), self._stream())
