@@ -196,14 +196,17 @@ def main():
     eng.profile(False)
     def burst_ms(fn, reps=40):
         """Sustained duration of one launch: `reps` back-to-back launches between two events on the launch stream,
-        queued behind a few ms of other GPU work (one candidate-scoring pass without a host read-back), so that all of
-        them are enqueued before the first one starts -- a 8-30 us kernel is otherwise timed at the host's launch
+        queued behind ~4 ms of a spin kernel (torch.cuda._sleep: occupies the stream, draws no power), so that all
+        of them are enqueued before the first one starts -- a 8-30 us kernel is otherwise timed at the host's launch
         rate (measured: Python + ctypes issue one launch per ~17 us).  A per-launch event bracket would add ~3 us."""
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
-        eng.predict(post, Xc, score=SCORE_POINTWISE_EI, mustar=mustar, want_mu=False, want_var=False, want_score=False,
-                    want_best=False)
+        if hasattr(torch.cuda, "_sleep"):
+            torch.cuda._sleep(10_000_000)
+        else:
+            eng.predict(post, Xc, score=SCORE_POINTWISE_EI, mustar=mustar, want_mu=False, want_var=False,
+                        want_score=False, want_best=False)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -215,11 +218,36 @@ def main():
     def gram_burst_ms(Xg, reps=40):
         out = eng.empty(Xg.shape[0], Xg.shape[0])      # one output buffer: no allocator traffic between launches
         return burst_ms(lambda: eng.gram(Xg, th, kern, out=out), reps)
-    eng.profile(True)
 
     # ---- candidates resident in HBM ----------------------------------------------------
     Xc = eng.dev(np.random.default_rng(1 + rank).random((M, D)))
     mustar = float(np.max(g["mu"]))
+
+    # ---- sustained rates of the HBM-bound kernels (rank 0; BEFORE the timed loop: after half a second of
+    # fp64-MFMA work the chip's power management runs memory-bound kernels ~30 % slower for a while,
+    # tools/alloc_effect.py: 23.3 -> 31.5 us for the N = 4096 Gram) ----------------------------------------------
+    gram_ms, gram_n, gram_sizes, pj_burst_ms = 0.0, 1, {}, None
+    F_RFF = 4096
+    if rank == 0:
+        gram_ms = gram_burst_ms(Xd)
+    if rank == 0 and not args.no_secondary:
+        # write-only floor of the chip for an N x N fp64 matrix, measured by tools/store_floor.hip
+        # (profiles/r01_gram_store_floor_v1.txt): the best any Gram kernel can reach at that N
+        floor_frac = {"2048": 0.69, "4096": 0.85, "8192": 0.82}
+        for Ng in (4096, 8192):   # SURVEY 7: the Gram roofline is only meaningful beyond the launch-latency regime
+            Xg = eng.dev(np.random.default_rng(7).random((Ng, D)))
+            gms = gram_burst_ms(Xg, 20)
+            gb = 8.0 * Ng * Ng + 8.0 * Ng * D
+            gram_sizes[str(Ng)] = {"avg_ms": gms, "achieved_GBs": gb / (gms * 1e-3) / 1e9,
+                                   "frac": gb / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                   "write_only_floor_frac": floor_frac[str(Ng)]}
+            del Xg
+        W_rff = eng.dev(np.random.default_rng(3).standard_normal((F_RFF, D)) / th[1])
+        b_rff = eng.dev(np.random.default_rng(4).uniform(0, 2 * np.pi, F_RFF))
+        Phi_out = eng.empty(F_RFF, N)
+        pj_burst_ms = burst_ms(lambda: eng.rff_project(Xd, W_rff, b_rff, th[2], out=Phi_out))
+        del Phi_out
+    eng.profile(True)
 
     def step():
         out = eng.predict(post, Xc, score=SCORE_POINTWISE_EI, mustar=mustar, want_mu=False, want_var=False,
@@ -248,7 +276,6 @@ def main():
     ks_ms, ks_n = eng.profile_read("kstar")
     sc_ms, sc_n = eng.profile_read("score")
     eng.profile(False)
-    gram_ms, gram_n = (gram_burst_ms(Xd), 1) if rank == 0 else (0.0, 1)
 
     # ---- secondary rows of SURVEY 8d (rank 0 only, outside the timed region) ------------
     secondary = {}
@@ -261,14 +288,9 @@ def main():
                 fn()
             torch.cuda.synchronize()
             return (time.perf_counter() - t1) / reps
-        F = 4096
-        W = eng.dev(np.random.default_rng(3).standard_normal((F, D)) / th[1])
-        b = eng.dev(np.random.default_rng(4).uniform(0, 2 * np.pi, F))
+        F, W, b = F_RFF, W_rff, b_rff
         om = eng.dev(np.random.default_rng(5).standard_normal(F))
         t_proj = timed(lambda: eng.rff_project(Xd, W, b, th[2]), 10)
-        Phi_out = eng.empty(F, N)
-        pj_burst_ms = burst_ms(lambda: eng.rff_project(Xd, W, b, th[2], out=Phi_out))
-        del Phi_out
         eng.profile(True)
         t_rs = timed(lambda: eng.rff_score(Xc, W, b, th[2], om, want_score=False), 5)
         rs_ms, rs_n = eng.profile_read("rff_score")
@@ -283,18 +305,6 @@ def main():
         z = eng.dev(rngl.standard_normal((S, G)))
         t_line = timed(lambda: eng.line_acq(post, gridd, z, mustar, jitter=1e-10 * float(th[2]) ** 2), 3)
         phi_bytes = 8.0 * F * N
-        gram_sizes = {}
-        # write-only floor of the chip for an N x N fp64 matrix, measured by tools/store_floor.hip
-        # (profiles/r01_gram_store_floor_v1.txt): the best any Gram kernel can reach at that N
-        floor_frac = {"2048": 0.69, "4096": 0.85, "8192": 0.82}
-        for Ng in (4096, 8192):   # SURVEY 7: the Gram roofline is only meaningful beyond the launch-latency regime
-            Xg = eng.dev(np.random.default_rng(7).random((Ng, D)))
-            gms = gram_burst_ms(Xg, 20)
-            gb = 8.0 * Ng * Ng + 8.0 * Ng * D
-            gram_sizes[str(Ng)] = {"avg_ms": gms, "achieved_GBs": gb / (gms * 1e-3) / 1e9,
-                                   "frac": gb / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                   "write_only_floor_frac": floor_frac[str(Ng)]}
-            del Xg
         secondary = {
             "gram_kernel_larger_N": gram_sizes,
             "rff_project": {"F": F, "wall_ms_per_call": t_proj * 1e3, "avg_ms": pj_burst_ms, "bytes": phi_bytes,
