@@ -1,25 +1,34 @@
 """Collapse the rocprofv3 --pmc passes written by tools/pmc_quadform.sh into one JSON: per hot kernel the
 per-launch average of every counter (dispatches of the same kernel averaged; multi-instance counters summed per
 dispatch by rocprofv3 already), plus the derived figures DESIGN.md quotes.
-usage: python tools/pmc_summary.py gpurun_out/pmc > profiles/rNN_pmc_hot_kernels_vK.json"""
+usage: python tools/pmc_summary.py gpurun_out/pmc > profiles/r02_pmc_hot_kernels.json"""
 import csv, glob, json, os, sys, collections
 
 root = sys.argv[1]
-HOT = {"quadform": "quadform_kernel", "kstar": "kstar_kernel", "gram_mfma": "gram_mfma_kernel", "score_kernel": "score_kernel"}
+HOT = {"quadform": "quadform_kernel", "kstar": "kstar_kernel", "gram_mfma": "gram_mfma_kernel", "score_kernel": "score_kernel",
+       "rff_project": "rff_project_kernel", "potrf_step": "potrf_step_kernel"}
 out = {k: {} for k in HOT}
 for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     per = collections.defaultdict(lambda: collections.defaultdict(float))   # (kernel, counter) -> dispatch -> value
+    grid = {}                                                                # (kernel, dispatch) -> grid size
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row.get("Kernel_Name", "")
             for key, pat in HOT.items():
                 if pat in name:
                     per[(key, row["Counter_Name"])][row["Dispatch_Id"]] += float(row["Counter_Value"])
+                    grid[(key, row["Dispatch_Id"])] = int(row["Grid_Size"])
     for (key, ctr), d in per.items():
-        vals = list(d.values())
+        # only the launches of the benchmark's own shape: the LARGEST grid of that kernel in the run (bench.py also
+        # scores 256-512 candidate check batches and the Gram kernel runs at three sizes)
+        gmax = max(grid[(key, disp)] for disp in d)
+        if key == "gram_mfma":             # the C3 design (N = 2048): the smallest grid
+            gmax = min(grid[(key, disp)] for disp in d)
+        vals = [v for disp, v in d.items() if grid[(key, disp)] == gmax]
         if key == "quadform" and len(vals) > 1:
             vals = vals[1:]                      # drop the warm-up launch
         out[key][ctr] = sum(vals) / len(vals)
+        out[key]["launches_averaged"] = len(vals)
 q = out["quadform"]
 if "SQ_INSTS_MFMA" in q:
     d = {}
@@ -34,4 +43,10 @@ if "SQ_INSTS_MFMA" in q:
     if "TCC_HIT_sum" in q and "TCC_MISS_sum" in q:
         d["l2_hit_rate"] = q["TCC_HIT_sum"] / (q["TCC_HIT_sum"] + q["TCC_MISS_sum"])
     q["derived"] = d
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+try:                                   # which kernel sources the counters belong to (bench.py compares it with the tree)
+    from ppbo_amd.build import _digest
+    out["csrc_digest"] = _digest()
+except Exception:
+    out["csrc_digest"] = None
 json.dump(out, sys.stdout, indent=1)
