@@ -234,6 +234,21 @@ int ppbo_laplace_logdet(ppbo_ctx* ctx, const double* d_Sigma, const double* d_la
                         const double* d_lam_off, int N, int m, double* h_u_sign, double* h_u_logdet,
                         int* h_info, void* stream);
 
+/* ---- (e) the path's one collective, over RCCL / xGMI ---------------------------------------------------
+ * Candidate rows are sharded over one process per GPU; every rank scores its shard with
+ * ppbo_predict and contributes (best score, GLOBAL row index).  ppbo_argmax_allgather is ONE ncclAllGather of a
+ * 16-byte record per rank followed by a local reduction: largest value, ties to the smallest index
+ * (np.argmax first-occurrence semantics), NaN or index < 0 never win.  librccl is dlopen'ed on first use.
+ *   rank 0:  ppbo_dist_unique_id(ctx, id)  -> ship the 128 bytes to the other ranks by any means (file, MPI, env)
+ *   all:     ppbo_dist_init(ctx, id, rank, world)   (collective; the ctx's device is the rank's GPU)
+ *   search:  ppbo_argmax_allgather(ctx, local_val, local_idx + shard_offset, &val, &idx, stream)
+ * Return codes 2000 + ncclResult_t for RCCL failures. */
+int ppbo_dist_unique_id(ppbo_ctx* ctx, void* h_id128);
+int ppbo_dist_init(ppbo_ctx* ctx, const void* h_id128, int rank, int world);
+int ppbo_dist_destroy(ppbo_ctx* ctx);
+int ppbo_argmax_allgather(ppbo_ctx* ctx, double local_val, int64_t local_global_idx, double* h_best_val,
+                          int64_t* h_best_idx, void* stream);
+
 /* y = op(A) x for a square fp64 matrix; lower != 0 reads only the lower triangle (A is then
  * treated as lower-triangular).  Used for alpha = Sigma^-1 f_MAP (src/gp_model.py:445) and
  * prior draws L z (src/gp_model.py:374). */

@@ -67,6 +67,10 @@ SIGNATURES = {
     "ppbo_lu_slogdet": [_vp, _vp, _i, _i, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i), _vp],
     "ppbo_laplace_logdet": [_vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i), _vp],
     "ppbo_dgemv": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
+    "ppbo_dist_unique_id": [_vp, _vp],
+    "ppbo_dist_init": [_vp, _vp, _i, _i],
+    "ppbo_dist_destroy": [_vp],
+    "ppbo_argmax_allgather": [_vp, _d, _i64, C.POINTER(_d), C.POINTER(_i64), _vp],
     "ppbo_dgemm": [_vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i, _d, _vp, _i, _vp],
 }
 

@@ -89,6 +89,7 @@ int ppbo_ctx_create(int device, ppbo_ctx** out) {
 
 int ppbo_ctx_destroy(ppbo_ctx* ctx) {
   if (!ctx) return 0;
+  if (ctx->dist) (void)ppbo_dist_destroy(ctx);
   {
   PpboDeviceGuard guard(ctx);
   (void)hipDeviceSynchronize();

@@ -13,13 +13,16 @@
 
 #include "../../include/ppbo_hip.h"
 
+struct PpboUniqueId { char internal[128]; };   // layout of ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+struct ppbo_dist_state;                          // dist.hip: the RCCL communicator of a ctx
+
 // A ctx owns private device workspaces (grown on demand, freed on destroy) and
 // the last error string.  No global mutable state.
 struct ppbo_ctx {
   int device = 0;
   std::string err;
   // named workspace slots
-  enum { WS_KSTAR = 0, WS_PART, WS_SCRATCH, WS_LINALG, WS_LINALG2, WS_VEC, WS_SMALL, WS_POTRF, WS_APPEND, WS_COUNT };
+  enum { WS_KSTAR = 0, WS_PART, WS_SCRATCH, WS_LINALG, WS_LINALG2, WS_VEC, WS_SMALL, WS_POTRF, WS_APPEND, WS_DIST, WS_COUNT };
   void* ws[WS_COUNT] = {};
   size_t ws_bytes[WS_COUNT] = {};
   void* pinned = nullptr;  // small pinned host staging buffer
@@ -33,6 +36,7 @@ struct ppbo_ctx {
   std::vector<const void*> lds_raised;
   // tuning knobs, read from the environment once per ctx (ppbo_ctx_create); defaults = measured best
   int qf_variant = 2, qf_order = 258, potrf_gen = 3, rff_nt = 0, gram_variant = 0;
+  ppbo_dist_state* dist = nullptr;   // set by ppbo_dist_init
 };
 
 // Every extern "C" entry runs on its ctx's device and leaves the caller's current device as it found it.

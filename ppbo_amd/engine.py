@@ -105,6 +105,22 @@ class Engine:
         md.kstar_fp32 = int(bool(kstar_fp32))
         return md
 
+    # ---- the path's collective behind the C-ABI (RCCL; no torch.distributed needed) -----------------
+    def dist_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.ppbo_dist_unique_id(self.ctx, buf), "ppbo_dist_unique_id")
+        return buf.raw
+
+    def dist_init(self, unique_id: bytes, rank: int, world: int):
+        self._check(self.lib.ppbo_dist_init(self.ctx, C.c_char_p(unique_id), int(rank), int(world)), "ppbo_dist_init")
+
+    def argmax_allgather(self, local_val: float, local_global_idx: int):
+        bv, bi = C.c_double(0.0), C.c_int64(-1)
+        rc = self.lib.ppbo_argmax_allgather(self.ctx, float(local_val), int(local_global_idx), C.byref(bv), C.byref(bi),
+                                            self._stream())
+        self._check(rc, "ppbo_argmax_allgather")
+        return bv.value, bi.value
+
     # ---- per-kernel event timing ---------------------------------------------
     def profile(self, on=True):
         self.lib.ppbo_profile_enable(self.ctx, int(on))

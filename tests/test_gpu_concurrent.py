@@ -100,3 +100,24 @@ def test_last_iteration_restarts_run_concurrently(golden):
     gp.update_fMAP(random_initial_vector=True, fmap_finding_trials=1)
     # every restart converges to the same optimum on this design; best-of-10 equals the single fit to the Newton gap
     assert np.abs(f_multi - gp.fMAP).max() <= 5e-5 * np.abs(gp.fMAP).max()
+
+
+def test_c_abi_collective_world_1():
+    """ppbo_dist_* / ppbo_argmax_allgather (RCCL, dlopen'ed) on a single rank: the record must come back unchanged
+    and the tie / NaN rules are the library's, not torch's.  (world > 1 needs several GPUs: bench.py --gpus N and the
+    torch.distributed path cover the same exchange; the driver's SCALE run exercises it.)"""
+    from ppbo_amd.engine import Engine
+    eng = Engine(0)
+    uid = eng.dist_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng.dist_init(uid, 0, 1)
+    assert eng.argmax_allgather(1.25, 4711) == (1.25, 4711)
+    v, i = eng.argmax_allgather(float("nan"), 3)
+    assert i == -1 and v != v
+    with pytest.raises(RuntimeError, match="twice"):
+        eng.dist_init(uid, 0, 1)
+    other = Engine(0)
+    with pytest.raises(RuntimeError, match="ppbo_dist_init has not been called"):
+        other.argmax_allgather(1.0, 1)
+    other.close()
+    eng.close()

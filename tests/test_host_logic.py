@@ -144,3 +144,26 @@ def test_next_query_matches_reference_outputs(name, acq, xacq):
         assert np.array_equal(xi == 0, x[key + "_xi"][k] == 0) and np.array_equal(xx == 0, x[key + "_x"][k] == 0)
         assert int(getattr(st, "dim_query_prev_iter", -1)) == int(x[key + "_dim"][k])
     assert np.array_equal(gp.xstar, x["xstar"])                 # the dispatcher must not mutate the model's x*
+
+
+def test_tgn_sampler_follows_the_reference_density():
+    """TGN grids (feedback_processing.py:87-95): the reference draws them by adaptive rejection sampling (arspy,
+    absent) from log_TGN_pdf (TGN_distribution.py:21-25).  tests/golden/tgn.npz holds that log-density evaluated by the
+    reference itself; our inverse-CDF sampler must (i) use exactly that density and (ii) produce samples whose
+    empirical distribution matches it (Kolmogorov-Smirnov)."""
+    import scipy.stats
+    from scipy.special import gamma as Gamma
+    from conftest import load_golden
+    from ppbo_amd.feedback_processing import _tgn_sample
+    g = load_golden("tgn")
+    rng = np.random.RandomState(0)
+    for (gam, al, a, b), x, lp in zip(g["cases"], g["x"], g["logpdf"]):
+        scale = Gamma(gam) * abs(b - a) / 10.0
+        dist = scipy.stats.gennorm(gam, loc=al, scale=scale)
+        mass = dist.cdf(b) - dist.cdf(a)
+        ours = dist.logpdf(x) - np.log(mass)                       # the density _tgn_sample inverts
+        assert np.abs(ours - lp).max() <= 1e-9 * max(1.0, np.abs(lp).max())
+        s = _tgn_sample(20000, gam, al, a, b, rng=rng)
+        assert s.min() >= a and s.max() <= b
+        cdf = lambda v: (dist.cdf(v) - dist.cdf(a)) / mass         # noqa: E731
+        assert scipy.stats.kstest(s, cdf).pvalue > 1e-3

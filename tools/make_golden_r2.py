@@ -13,7 +13,7 @@ in-memory shims as tools/make_golden.py, nothing copied).  They pin what round 1
                 Hsampler.return_xstar for the stored omega (random_fourier_sampler.py:143-176), evidence
                 (gp_model.py:278-319) at three thetas.
 
-usage: python tools/make_golden_r2.py g7 | extras smoke rq c2 c4 c3
+usage: python tools/make_golden_r2.py g7 | tgn | extras smoke rq c2 c4 c3
 """
 from __future__ import annotations
 
@@ -235,6 +235,21 @@ def extras(name, do_evidence):
     print(f"[{name}_x] wrote {path} ({os.path.getsize(path) / 1e3:.0f} kB) in {time.time() - t0:.0f}s", flush=True)
 
 
+def tgn():
+    """The reference's truncated-generalised-normal log-density (src/TGN_distribution.py:21-25) on grids: the
+    sampler itself is arspy's adaptive rejection sampling (absent here), the DENSITY it samples is pinned by these."""
+    import TGN_distribution as ref_tgn        # imports with the arspy stub; only log_TGN_pdf is used
+    cases = [(5.0, 0.3, 0.0, 1.0), (2.0, -1.2, -3.0, 3.0), (2.6, 0.95, 0.0, 1.0), (3.5, 4.0, 4.0, 7.0), (2.05, 10.0, -180.0, 180.0)]
+    xs, lp = [], []
+    for gam, al, a, b in cases:
+        x = np.linspace(a, b, 401)
+        xs.append(x)
+        lp.append(np.array([float(ref_tgn.log_TGN_pdf(v, gam, al, a, b)) for v in x]))
+    path = os.path.join(OUT, "tgn.npz")
+    np.savez_compressed(path, cases=np.array(cases), x=np.stack(xs), logpdf=np.stack(lp))
+    print(f"[tgn] wrote {path}")
+
+
 if __name__ == "__main__":
     mg.install_shims()
     args = sys.argv[1:]
@@ -242,6 +257,8 @@ if __name__ == "__main__":
         sys.exit(__doc__)
     if args[0] == "g7":
         g7()
+    elif args[0] == "tgn":
+        tgn()
     elif args[0] == "extras":
         for nm in args[1:]:
             extras(nm, do_evidence=(nm in ("c2",)))
