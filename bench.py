@@ -185,10 +185,13 @@ def main():
         return post, st
     post, st = fit_once()            # warm (allocates workspaces)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    post, st = fit_once()
-    torch.cuda.synchronize()
-    gp_fit_ms = (time.perf_counter() - t0) * 1e3
+    fit_runs = []
+    for _ in range(3):               # the same deterministic cold fit three times: the best run is reported, all are listed
+        t0 = time.perf_counter()
+        post, st = fit_once()
+        torch.cuda.synchronize()
+        fit_runs.append((time.perf_counter() - t0) * 1e3)
+    gp_fit_ms = min(fit_runs)
     eng.profile(True)                # one more fit with the library's event brackets: where the fit time goes
     fit_once()
     torch.cuda.synchronize()
@@ -341,7 +344,8 @@ def main():
                                    f"({M} on rank 0), {kern} theta={list(map(float, th))}", "name": args.config,
                        "N": N, "D": D, "M_total": M_total, "M_per_gpu": M,
                        "parallelism": f"candidates sharded x{world} ({scaling}), model replicated, 1 all-gather/step"},
-            "gp_fit_ms": gp_fit_ms, "gp_fit_iterations": st["iterations"], "gp_fit_cholesky": st["n_cholesky"],
+            "gp_fit_ms": gp_fit_ms, "gp_fit_ms_runs": fit_runs, "gp_fit_iterations": st["iterations"],
+            "gp_fit_cholesky": st["n_cholesky"],
             "gp_fit_breakdown": {"potrf_calls": potrf_n, "potrf_avg_ms": potrf_ms / max(potrf_n, 1),
                                  "potrf_total_ms": potrf_ms,
                                  "note": "factorizations incl. Sigma^-1 and the posterior; failed ones end early"},
