@@ -344,6 +344,40 @@ def test_rff_vs_reference(eng, golden, name):
     assert bi == int(np.argmax(host(sc))) and bv == host(sc).max()
 
 
+@pytest.mark.parametrize("N,F,D", [(1, 1, 1), (63, 65, 3), (130, 70, 7), (257, 130, 20), (1000, 300, 33), (514, 4100, 6)])
+@pytest.mark.parametrize("nt", ["1", "2", "4"])
+def test_rff_project_ragged_shapes(N, F, D, nt):
+    """Odd N takes the 8-byte store path, even N the 16-byte row-pair path; every strip length; F, N, D ragged
+    against the 64-wide tiles and the depth buckets; phases far outside the branch-free cosine's range take the
+    library path behind the wave-uniform branch."""
+    import os
+    from ppbo_amd.engine import Engine
+    os.environ["PPBO_RFF_NT"] = nt
+    try:
+        e = Engine(0)                      # the knob is read once per ctx
+    finally:
+        os.environ.pop("PPBO_RFF_NT", None)
+    rng = np.random.default_rng(N + F + D)
+    X = rng.random((N, D))
+    W = rng.standard_normal((F, D)) / 0.1
+    b = rng.uniform(0, 2 * np.pi, F)
+    if F > 2:
+        W[1] *= 1e6                          # |w.x| ~ 1e7: beyond the fast range
+        b[2] = 3e7
+    Phi = host(e.rff_project(X, W, b, 0.7))
+    ref = orc.rff_features(X, W, b, 0.7)
+    assert Phi.shape == (F, N)
+    # a phase of 1e7 carries 1e7 * eps of argument rounding in ANY double evaluation of w.x + b
+    tol = np.full((F, 1), 1e-12)
+    if F > 2:
+        tol[1] = tol[2] = 1e-8
+    assert np.all(np.abs(Phi - ref) <= tol * np.sqrt(2 * 0.49 / F) * 10 + 1e-16)
+    om = rng.standard_normal(F)
+    sc, bv, bi = e.rff_score(X, W, b, 0.7, om)
+    assert np.abs(host(sc) - ref.T @ om).max() <= 1e-7 * np.abs(ref.T @ om).max() + 1e-12
+    e.close()
+
+
 # ---------------------------------------------------------------- full-size properties (BASELINE config C3)
 @pytest.mark.skipif("c3" not in ALL, reason="c3 fixture missing")
 def test_full_size_c3_properties(eng, golden):
