@@ -588,3 +588,32 @@ def test_c4_sharded_search_equals_single_search(eng, golden):
     v, i = combine_best(torch.tensor(vals, dtype=torch.float64), torch.tensor(idxs))
     # same winner; the value may differ in the last bit (the row-split partial sums are grouped per launch size)
     assert i == full["best_idx"] and abs(v - full["best_val"]) <= 1e-12 * abs(full["best_val"])
+
+
+@pytest.mark.parametrize("G", [90, 128])
+def test_line_acq_long_grids(eng, golden, G):
+    """G up to the documented 128 points per line: beyond ~89 the per-line Cholesky needs more than the default
+    64 KB of dynamic LDS (133 KB at G = 128), which the library raises per ctx; G = 129 is an argument error."""
+    g = golden("smoke")
+    post, _ = _posterior(eng, g)
+    D = int(g["D"])
+    rng = np.random.default_rng(G)
+    al = np.linspace(0.005, 0.995, G)
+    grids = []
+    for b in range(3):
+        xi = np.zeros(D); xi[b % D] = 1.0
+        x = rng.random(D); x[b % D] = 0.0
+        grids.append(orc.line_grid(xi, x, al))
+    grid = np.stack(grids)
+    z = rng.standard_normal((150, G))
+    sf2 = float(g["theta"][2]) ** 2
+    mustar, jit = float(g["line_mustar"]), 1e-9 * sf2
+    ei, vm = eng.line_acq(post, grid, z, mustar, jitter=jit)
+    for b in range(3):
+        mu_b, cov_b = eng.predict_cov(post, grid[b])
+        e0 = orc.line_ei(host(mu_b), host(cov_b), z, mustar, jitter=jit)
+        v0 = orc.line_varmax(host(mu_b), host(cov_b), z, jitter=jit)
+        assert abs(host(ei)[b] - e0) <= 1e-6 * max(abs(e0), 1e-3 * np.sqrt(sf2))
+        assert abs(host(vm)[b] - v0) <= 1e-5 * max(abs(v0), 1e-6 * sf2)
+    with pytest.raises(RuntimeError, match="G <= 128"):
+        eng.line_acq(post, np.zeros((1, 129, D)), rng.standard_normal((10, 129)), mustar)
