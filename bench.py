@@ -154,14 +154,23 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py: no ROCm GPU visible (torch.cuda.is_available() is False); the product has no CPU path")
+    # PPBO_BENCH_SHARE_GPU=1 (tests only): every rank uses cuda:0 and the collectives run over gloo on host
+    # tensors -- RCCL refuses two ranks on one device, and this build environment only has 1-GPU boxes; it
+    # exercises the whole multi-rank control flow (sharding, barriers, max-over-ranks timing, the argmax exchange)
+    share_gpu = os.environ.get("PPBO_BENCH_SHARE_GPU") == "1"
+    gpu_index = 0 if share_gpu else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    eng = Engine(local_rank)
+        torch.cuda.set_device(gpu_index)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+    eng = Engine(gpu_index)
     dev = eng.device
+    coll_dev = torch.device("cpu") if share_gpu else dev       # where the collectives' tensors live
 
     g = synth_model_inputs(args.config)
     X, th, m, kern = g["X"], g["theta"], int(g["m"]), str(g["kernel"])
@@ -256,7 +265,7 @@ def main():
         out = eng.predict(post, Xc, score=SCORE_POINTWISE_EI, mustar=mustar, want_mu=False, want_var=False,
                           want_score=False, want_best=True)
         gidx = out["best_idx"] + row_lo
-        return allgather_argmax(out["best_val"], gidx, device=dev)
+        return allgather_argmax(out["best_val"], gidx, device=coll_dev)
 
     for _ in range(args.warmup):
         step()
@@ -272,7 +281,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     qf_ms, qf_n = eng.profile_read("quadform")
@@ -343,7 +352,8 @@ def main():
             "config": {"workload": f"{wl_name}: N={N} obs rows (m={m}), D={D}, M={M_total} candidates in total "
                                    f"({M} on rank 0), {kern} theta={list(map(float, th))}", "name": args.config,
                        "N": N, "D": D, "M_total": M_total, "M_per_gpu": M,
-                       "parallelism": f"candidates sharded x{world} ({scaling}), model replicated, 1 all-gather/step"},
+                       "parallelism": f"candidates sharded x{world} ({scaling}), model replicated, 1 all-gather/step"
+                                      + (" [TEST MODE: ranks share one GPU, gloo]" if share_gpu else "")},
             "gp_fit_ms": gp_fit_ms, "gp_fit_ms_runs": fit_runs, "gp_fit_iterations": st["iterations"],
             "gp_fit_cholesky": st["n_cholesky"],
             "gp_fit_breakdown": {"potrf_calls": potrf_n, "potrf_avg_ms": potrf_ms / max(potrf_n, 1),

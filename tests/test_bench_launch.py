@@ -60,3 +60,25 @@ def test_gpus_1_line_is_well_formed():
     assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["config"]["name"] == "c2"
     assert 0 < line["roofline"]["frac"] <= 1.0 and line["roofline"]["traffic"] is None
     assert line["roofline"]["dense_equivalent_tflops"] >= line["roofline"]["achieved"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_two_ranks_sharing_one_gpu(scaling):
+    """The multi-rank control flow of bench.py on a 1-GPU box: two ranks on cuda:0, collectives over gloo
+    (PPBO_BENCH_SHARE_GPU=1; RCCL refuses two ranks per device).  Sharding, barriers, the max-over-ranks timing and the
+    argmax exchange are the code the 8-GPU run uses; only the backend differs."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "c2", "--scaling", scaling,
+              "--no-cpu-baseline", "--no-secondary"], {"PPBO_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling
+    if scaling == "strong":
+        assert line["config"]["M_total"] == 16384 and line["config"]["M_per_gpu"] == 8192
+    else:
+        assert line["config"]["M_total"] == 32768 and line["config"]["M_per_gpu"] == 16384
+    assert 0 <= line["best"]["index"] < line["config"]["M_total"]
+    assert abs(line["value"] - line["config"]["M_total"] * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
+    assert "TEST MODE" in line["config"]["parallelism"]
