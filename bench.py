@@ -207,25 +207,35 @@ def main():
     potrf_ms, potrf_n = eng.profile_read("potrf")
     eng.profile(False)
     def burst_ms(fn, reps=40):
-        """Sustained duration of one launch: `reps` back-to-back launches between two events on the launch stream,
-        queued behind ~4 ms of a spin kernel (torch.cuda._sleep: occupies the stream, draws no power), so that all
-        of them are enqueued before the first one starts -- a 8-30 us kernel is otherwise timed at the host's launch
-        rate (measured: Python + ctypes issue one launch per ~17 us).  A per-launch event bracket would add ~3 us."""
+        """Steady-state duration of one launch of a SHORT kernel (8-100 us).  100 launches are captured in a HIP graph
+        (torch.cuda.CUDAGraph over the stream the C-ABI launches on) and the graph is replayed back to back for tens
+        of milliseconds, so that (a) the host's launch rate is out of the picture -- Python + ctypes issue one
+        launch per ~17 us, which IS the duration of these kernels -- and (b) the clocks have settled under the
+        kernel's own load (after an idle spell or a spin kernel the same kernel runs ~10 % slower, after half a
+        second of fp64 MFMA work ~30 % slower: tools/alloc_effect.py, tools/dev/rff_ctx_effect.py).  The last half
+        of the replays is timed with one event pair."""
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
-        if hasattr(torch.cuda, "_sleep"):
-            torch.cuda._sleep(10_000_000)
-        else:
-            eng.predict(post, Xc, score=SCORE_POINTWISE_EI, mustar=mustar, want_mu=False, want_var=False,
-                        want_score=False, want_best=False)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+        per_graph, replays = max(10, min(100, reps * 2)), 40
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
             fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(per_graph):
+                    fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for r in range(replays):
+            if r == replays // 2:
+                e0.record()
+            graph.replay()
         e1.record()
         e1.synchronize()
-        return e0.elapsed_time(e1) / reps
+        return e0.elapsed_time(e1) / ((replays - replays // 2) * per_graph)
 
     def gram_burst_ms(Xg, reps=40):
         out = eng.empty(Xg.shape[0], Xg.shape[0])      # one output buffer: no allocator traffic between launches
@@ -235,14 +245,17 @@ def main():
     Xc = eng.dev(np.random.default_rng(1 + rank).random((M, D)))
     mustar = float(np.max(g["mu"]))
 
-    # ---- sustained rates of the HBM-bound kernels (rank 0; BEFORE the timed loop: after half a second of
-    # fp64-MFMA work the chip's power management runs memory-bound kernels ~30 % slower for a while,
-    # tools/alloc_effect.py: 23.3 -> 31.5 us for the N = 4096 Gram) ----------------------------------------------
+    # ---- steady-state rates of the HBM-bound kernels (rank 0), each under its own load (see burst_ms) ---------
     gram_ms, gram_n, gram_sizes, pj_burst_ms = 0.0, 1, {}, None
     F_RFF = 4096
     if rank == 0:
         gram_ms = gram_burst_ms(Xd)
     if rank == 0 and not args.no_secondary:
+        W_rff = eng.dev(np.random.default_rng(3).standard_normal((F_RFF, D)) / th[1])
+        b_rff = eng.dev(np.random.default_rng(4).uniform(0, 2 * np.pi, F_RFF))
+        Phi_out = eng.empty(F_RFF, N)
+        pj_burst_ms = burst_ms(lambda: eng.rff_project(Xd, W_rff, b_rff, th[2], out=Phi_out))
+        del Phi_out
         # write-only floor of the chip for an N x N fp64 matrix, measured by tools/store_floor.hip
         # (profiles/r01_gram_store_floor_v1.txt): the best any Gram kernel can reach at that N
         floor_frac = {"2048": 0.69, "4096": 0.85, "8192": 0.82}
@@ -254,11 +267,6 @@ def main():
                                    "frac": gb / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                    "write_only_floor_frac": floor_frac[str(Ng)]}
             del Xg
-        W_rff = eng.dev(np.random.default_rng(3).standard_normal((F_RFF, D)) / th[1])
-        b_rff = eng.dev(np.random.default_rng(4).uniform(0, 2 * np.pi, F_RFF))
-        Phi_out = eng.empty(F_RFF, N)
-        pj_burst_ms = burst_ms(lambda: eng.rff_project(Xd, W_rff, b_rff, th[2], out=Phi_out))
-        del Phi_out
     eng.profile(True)
 
     def step():
@@ -322,8 +330,8 @@ def main():
             "rff_project": {"F": F, "wall_ms_per_call": t_proj * 1e3, "avg_ms": pj_burst_ms, "bytes": phi_bytes,
                             "bound": "hbm", "achieved_GBs": phi_bytes / (pj_burst_ms * 1e-3) / 1e9,
                             "frac": phi_bytes / (pj_burst_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                            "note": "avg_ms = back-to-back launches between two events, queued behind a blocker (sustained GPU "
-                                    "rate); wall = one call incl. allocation and host launch latency"},
+                            "note": "avg_ms = steady state (HIP-graph replay of 100 launches); wall = one call incl. allocation "
+                                    "and host launch latency"},
             "rff_score_evals_per_s": M / t_rs, "rff_score_kernel_ms": rs_ms / max(rs_n, 1),
             "line_acq": {"lines": B, "grid": G, "draws": S, "ms": t_line * 1e3, "lines_per_s": B / t_line},
         }
@@ -374,9 +382,10 @@ def main():
                                 "peak_GBs": PEAK_HBM_GBS,
                                 "frac": gram_bytes / (gram_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if gram_avg_ms else None,
                                 "write_only_floor_frac": 0.69,
-                                "note": "back-to-back launches between two events, queued behind a blocker; the chip absorbs a "
-                                        "write-only 2048 x 2048 fp64 matrix at 0.69 of 8 TB/s with write-through stores "
-                                        "(tools/store_floor.hip): at this N a third of the kernel is launch ramp and drain"},
+                                "note": "steady state: HIP-graph replay of 100 launches, clocks settled under the kernel's own "
+                                        "load; the chip absorbs a write-only 2048 x 2048 fp64 matrix at 0.69 of 8 TB/s with "
+                                        "write-through stores (tools/store_floor.hip): at this N a third of the kernel is "
+                                        "launch ramp and drain"},
             },
             "secondary": secondary,
             "best": {"value": best[0], "index": best[1]},
