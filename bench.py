@@ -186,6 +186,14 @@ def main():
     # ---- GP fit (untimed for the step metric, reported as gp_fit_ms) -------------------
     Xd = eng.dev(X)
     f_init = eng.dev(g["f_init"])
+    fit_start = "the fixture's stored prior draw (default_rng(2), SURVEY 8d)"
+    if bool(g.get("f_init_is_warm_start", False)):
+        # C5's stored start is a near-optimal vector (the reference's own cold fit takes > 15 h): time the COLD fit from
+        # a prior draw L z instead, as tools/c5_start.py / tests/test_gpu_c5.py do
+        Ls = eng.potrf_(eng.gram(Xd, th, kern).clone())
+        f_init = eng.dgemv(Ls, np.random.default_rng(2).standard_normal(N), lower=True)
+        del Ls
+        fit_start = "prior draw L z, z = default_rng(2) (the fixture's own start is a warm start)"
     def fit_once():
         Sigma = eng.gram(Xd, th, kern)
         Sinv = eng.pd_inverse(Sigma)
@@ -195,7 +203,7 @@ def main():
     post, st = fit_once()            # warm (allocates workspaces)
     torch.cuda.synchronize()
     fit_runs = []
-    for _ in range(3):               # the same deterministic cold fit three times: the best run is reported, all are listed
+    for _ in range(3 if N <= 2048 else 1):   # the same deterministic cold fit (three times up to N = 2048): best run reported, all listed
         t0 = time.perf_counter()
         post, st = fit_once()
         torch.cuda.synchronize()
@@ -343,11 +351,13 @@ def main():
         mblk = m + 1
         # algorithmic flops of the variance contraction per launch: 2 M N^2 (dense A);
         # executed: the block-triangular G form does M * sum_tiles 2*128*kend(tile) flops
-        algo_flops = 2.0 * M * N * N
+        # one launch scores a chunk of <= 65536 candidates (ppbo_predict's chunk_cap); the average is over launches
+        M_launch = float(M) / max(1, -(-M // 65536))
+        algo_flops = 2.0 * M_launch * N * N
         # executed: each wavefront owns 32 rows of a 128-row tile and stops at the end of their last star block
         # (equals SQ_INSTS_MFMA x 2048 of the rocprofv3 --pmc pass, profiles/)
         wrows = 32
-        exec_flops = sum(2.0 * wrows * M * min(N, -(-((b + 1) * wrows) // mblk) * mblk) for b in range(-(-N // wrows)))
+        exec_flops = sum(2.0 * wrows * M_launch * min(N, -(-((b + 1) * wrows) // mblk) * mblk) for b in range(-(-N // wrows)))
         dense_equiv = algo_flops / (qf_avg_ms * 1e-3) / 1e12
         executed = exec_flops / (qf_avg_ms * 1e-3) / 1e12
         gram_bytes = 8.0 * N * N + 8.0 * N * D
@@ -362,7 +372,7 @@ def main():
                        "N": N, "D": D, "M_total": M_total, "M_per_gpu": M,
                        "parallelism": f"candidates sharded x{world} ({scaling}), model replicated, 1 all-gather/step"
                                       + (" [TEST MODE: ranks share one GPU, gloo]" if share_gpu else "")},
-            "gp_fit_ms": gp_fit_ms, "gp_fit_ms_runs": fit_runs, "gp_fit_iterations": st["iterations"],
+            "gp_fit_ms": gp_fit_ms, "gp_fit_ms_runs": fit_runs, "gp_fit_start": fit_start, "gp_fit_iterations": st["iterations"],
             "gp_fit_cholesky": st["n_cholesky"],
             "gp_fit_breakdown": {"potrf_calls": potrf_n, "potrf_avg_ms": potrf_ms / max(potrf_n, 1),
                                  "potrf_total_ms": potrf_ms,

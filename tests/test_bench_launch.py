@@ -82,3 +82,15 @@ def test_two_ranks_sharing_one_gpu(scaling):
     assert 0 <= line["best"]["index"] < line["config"]["M_total"]
     assert abs(line["value"] - line["config"]["M_total"] * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
     assert "TEST MODE" in line["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_chunked_config_keeps_the_roofline_fraction_below_one():
+    """C4 scores 262144 candidates in four 65536-candidate launches per step: the per-launch flops must be priced per
+    launch (a first version priced the whole step against one launch's time: frac 3.2)."""
+    r = _run(["--steps", "2", "--warmup", "1", "--config", "c4", "--no-cpu-baseline", "--no-secondary"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["config"]["M_total"] == 262144
+    assert 0 < line["roofline"]["frac"] <= 1.0
+    assert line["roofline"]["launches"] == 4 * 2
