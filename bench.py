@@ -225,25 +225,38 @@ def main():
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
-        per_graph, replays = max(10, min(100, reps * 2)), 40
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            fn()
+        try:
+            per_graph, replays = max(10, min(100, reps * 2)), 40
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                fn()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(per_graph):
+                        fn()
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph, stream=side):
-                for _ in range(per_graph):
-                    fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for r in range(replays):
-            if r == replays // 2:
-                e0.record()
-            graph.replay()
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / ((replays - replays // 2) * per_graph)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for r in range(replays):
+                if r == replays // 2:
+                    e0.record()
+                graph.replay()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / ((replays - replays // 2) * per_graph)
+        except Exception as exc:      # noqa: BLE001  -- graph capture unavailable: plain burst behind a blocker kernel
+            print(f"bench.py: HIP-graph capture failed ({exc!r}); timing a plain burst instead", file=sys.stderr)
+            torch.cuda.synchronize()
+            if hasattr(torch.cuda, "_sleep"):
+                torch.cuda._sleep(40_000_000)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps
 
     def gram_burst_ms(Xg, reps=40):
         out = eng.empty(Xg.shape[0], Xg.shape[0])      # one output buffer: no allocator traffic between launches
