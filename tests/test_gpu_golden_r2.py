@@ -214,3 +214,29 @@ def test_evidence_c2_vs_reference(golden):
         gp._draw_prior = lambda f0=f0: gp.eng.dev(f0)
         mine = gp.evidence(list(th), None)
         assert abs(mine - float(v)) <= 1e-5 * max(1.0, abs(float(v))), (list(th), mine, float(v))
+
+
+@pytest.mark.parametrize("name", ["smoke", "c2"])
+def test_return_xstar_for_dim_at_least_as_good_as_reference(golden, name):
+    """random_fourier_sampler.py:180-204: the reference optimises ONE coordinate by Nelder-Mead from GP_xstar; ours scores
+    a 4096-point grid of that coordinate in one launch.  Arithmetic parity at the reference's points, and our value
+    within the grid resolution of (or above) the reference's."""
+    from ppbo_amd.random_fourier_sampler import Hsampler
+    x = load_golden(name + "_x")
+    g, gp, st = _fitted(golden, name)
+    gp.xstar, gp.mustar = x["xstar"].copy(), float(x["mustar"])
+    gp.xstars_local = x["xstars_local"].copy()
+    F = g["rff_W"].shape[0]
+    hs = Hsampler(gp, F)
+    hs.W, hs.b = g["rff_W"].copy(), g["rff_b"].reshape(F, 1).copy()
+    hs.update_phi_X()
+    om = g["rff_omega"]
+    for dim in range(1, gp.D + 1):
+        xr, vr = x["rff_xstar_dim"][dim - 1], float(x["rff_xstar_dim_val"][dim - 1])
+        assert abs(float(np.dot(hs.phi(xr).T, om)) - vr) <= 1e-9 * max(abs(vr), 1e-6)
+        xo = hs.return_xstar_for_dim(om, dim, x["xstar"].copy())
+        others = [d for d in range(gp.D) if d != dim - 1]
+        assert np.array_equal(xo[others], x["xstar"][others]) and 0.0 <= xo[dim - 1] <= 1.0
+        vo = float(np.dot(hs.phi(xo).T, om))
+        # a 1/4095 grid misses a smooth maximum by at most |f''| h^2 / 8; the RFF surface has |f''| <= sum |w_d|^2 |omega| ...
+        assert vo >= vr - 1e-4 * max(abs(vr), np.abs(om).max() * 0.01), (dim, vo, vr)

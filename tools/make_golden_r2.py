@@ -235,6 +235,29 @@ def extras(name, do_evidence):
     print(f"[{name}_x] wrote {path} ({os.path.getsize(path) / 1e3:.0f} kB) in {time.time() - t0:.0f}s", flush=True)
 
 
+def augment_rff_dim(name):
+    """Add Hsampler.return_xstar_for_dim outputs (random_fourier_sampler.py:180-204, Nelder-Mead per coordinate from
+    GP_xstar) to an existing <name>_x.npz without touching what is already in it."""
+    import random_fourier_sampler as ref_rff
+    gp, st, z, ref_gp, ref_settings = _model_from_fixture(name)
+    path = os.path.join(OUT, f"{name}_x.npz")
+    x = dict(np.load(path))
+    gp.xstar, gp.mustar, gp.xstars_local = x["xstar"].copy(), float(x["mustar"]), x["xstars_local"].copy()
+    F = z["rff_W"].shape[0]
+    hs = ref_rff.Hsampler(gp, F)
+    hs.W, hs.b = z["rff_W"].copy(), z["rff_b"].reshape(F, 1).copy()
+    hs.update_phi_X()
+    om = z["rff_omega"]
+    pts, vals = [], []
+    for dim in range(1, gp.D + 1):
+        xr = hs.return_xstar_for_dim(om, dim, x["xstar"].copy())
+        pts.append(np.array(xr))
+        vals.append(float(np.dot(hs.phi(xr).T, om)))
+    x.update(rff_xstar_dim=np.array(pts), rff_xstar_dim_val=np.array(vals))
+    np.savez_compressed(path, **x)
+    print(f"[{name}_x] return_xstar_for_dim values {np.round(vals, 6)}")
+
+
 def tgn():
     """The reference's truncated-generalised-normal log-density (src/TGN_distribution.py:21-25) on grids: the
     sampler itself is arspy's adaptive rejection sampling (absent here), the DENSITY it samples is pinned by these."""
@@ -259,6 +282,9 @@ if __name__ == "__main__":
         g7()
     elif args[0] == "tgn":
         tgn()
+    elif args[0] == "augment-rff-dim":
+        for nm in args[1:]:
+            augment_rff_dim(nm)
     elif args[0] == "extras":
         for nm in args[1:]:
             extras(nm, do_evidence=(nm in ("c2",)))
