@@ -258,6 +258,33 @@ def augment_rff_dim(name):
     print(f"[{name}_x] return_xstar_for_dim values {np.round(vals, 6)}")
 
 
+def augment_omega_map(name):
+    """Add Hsampler.update_omega_MAP / update_covariancematrix outputs (random_fourier_sampler.py:124-140) at the fixture's
+    F (c2: F = 1000; round 1 only had F = 96) to <name>_x.npz; the start vector replaces the reference's randn draw."""
+    import random_fourier_sampler as ref_rff
+    gp, st, z, ref_gp, ref_settings = _model_from_fixture(name)
+    path = os.path.join(OUT, f"{name}_x.npz")
+    x = dict(np.load(path))
+    gp.xstar, gp.mustar, gp.xstars_local = x["xstar"].copy(), float(x["mustar"]), x["xstars_local"].copy()
+    F = z["rff_W"].shape[0]
+    hs = ref_rff.Hsampler(gp, F)
+    hs.W, hs.b = z["rff_W"].copy(), z["rff_b"].reshape(F, 1).copy()
+    hs.update_phi_X()
+    om0 = np.random.default_rng(6).standard_normal(F)
+    _randn = np.random.randn
+    np.random.randn = lambda *a: om0.copy()
+    t0 = time.time()
+    try:
+        hs.update_omega_MAP()
+    finally:
+        np.random.randn = _randn
+    hs.update_covariancematrix()
+    x.update(rff_omega0=om0, rff_omega_MAP=hs.omega_MAP, rff_cov_diag=np.diag(hs.covariance).copy(),
+             rff_S_at_MAP=float(hs.S(hs.omega_MAP, hs.theta)))
+    np.savez_compressed(path, **x)
+    print(f"[{name}_x] omega_MAP F={F}: S = {x['rff_S_at_MAP']:.8f} in {time.time() - t0:.0f}s")
+
+
 def tgn():
     """The reference's truncated-generalised-normal log-density (src/TGN_distribution.py:21-25) on grids: the
     sampler itself is arspy's adaptive rejection sampling (absent here), the DENSITY it samples is pinned by these."""
@@ -282,6 +309,9 @@ if __name__ == "__main__":
         g7()
     elif args[0] == "tgn":
         tgn()
+    elif args[0] == "augment-omega-map":
+        for nm in args[1:]:
+            augment_omega_map(nm)
     elif args[0] == "augment-rff-dim":
         for nm in args[1:]:
             augment_rff_dim(nm)
