@@ -226,6 +226,8 @@ def main():
             fn()
         torch.cuda.synchronize()
         try:
+            if world > 1:       # never capture while an RCCL watchdog thread is polling events in this process
+                raise RuntimeError("multi-rank run")
             per_graph, replays = max(10, min(100, reps * 2)), 40
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -233,7 +235,7 @@ def main():
             with torch.cuda.stream(side):
                 fn()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(graph, stream=side):
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                     for _ in range(per_graph):
                         fn()
             torch.cuda.synchronize()
@@ -246,7 +248,8 @@ def main():
             e1.synchronize()
             return e0.elapsed_time(e1) / ((replays - replays // 2) * per_graph)
         except Exception as exc:      # noqa: BLE001  -- graph capture unavailable: plain burst behind a blocker kernel
-            print(f"bench.py: HIP-graph capture failed ({exc!r}); timing a plain burst instead", file=sys.stderr)
+            if world == 1:
+                print(f"bench.py: HIP-graph capture failed ({exc!r}); timing a plain burst instead", file=sys.stderr)
             torch.cuda.synchronize()
             if hasattr(torch.cuda, "_sleep"):
                 torch.cuda._sleep(40_000_000)
