@@ -143,3 +143,30 @@ def test_optimize_theta_finds_the_evidence_ridge(golden):
     np.random.seed(12)
     # the value is a property of theta, not of the start draw (both fits stop at SciPy's gtol = 1e-4)
     assert abs(gp.evidence(gp.theta, None) - best) <= 1e-2 * max(1.0, abs(best))
+
+
+def test_contexts_on_two_devices_in_one_process(golden):
+    """The round-1 advisory scenario: get_engine(1) after get_engine(0) must not redirect engine 0's workspaces or LDS
+    attributes to GPU 1 (every entry point now runs under a device guard; attributes are per ctx).  Needs 2 GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs in one process")
+    from ppbo_amd.engine import Engine
+    g = golden("c2")
+    X, th, m, kern = g["X"], g["theta"], int(g["m"]), str(g["kernel"])
+    e0, e1 = Engine(0), Engine(1)
+    res = []
+    for eng in (e0, e1, e0):                      # alternate: the current device changes under engine 0's feet
+        S = eng.gram(X, th, kern)
+        Sinv = eng.pd_inverse(S)
+        fm, _ = eng.fit_fmap(Sinv, g["f_init"], m, th[0], gtol=1e-6)
+        post = eng.posterior(X, th, kern, Sinv, fm, m)
+        pr = eng.predict(post, g["Xc"])
+        assert S.device == eng.device and pr["mu"].device == eng.device
+        res.append((host(fm), host(pr["mu"]), host(pr["var"])))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    for a, b in zip(res[0], res[2]):
+        assert np.array_equal(a, b)
+    assert torch.cuda.current_device() == 0       # the library restored the caller's device every time
+    e0.close(); e1.close()
