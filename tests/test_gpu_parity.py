@@ -617,3 +617,39 @@ def test_line_acq_long_grids(eng, golden, G):
         assert abs(host(vm)[b] - v0) <= 1e-5 * max(abs(v0), 1e-6 * sf2)
     with pytest.raises(RuntimeError, match="G <= 128"):
         eng.line_acq(post, np.zeros((1, 129, D)), rng.standard_normal((10, 129)), mustar)
+
+
+@pytest.mark.parametrize("D", [1, 11, 13, 17, 23, 24, 30, 33, 47, 48, 50, 64])
+@pytest.mark.parametrize("kernel", ["SE_kernel", "RQ_kernel"])
+def test_every_dimension_bucket(eng, D, kernel):
+    """The kernels are specialised on the padded dimension (4 .. 64 in nine buckets for Gram / K* / RFF): one small
+    end-to-end check per bucket edge against the oracle -- Gram, cross-covariance, posterior mean / variance of a
+    Laplace posterior, the analytic mean gradient and the RFF features."""
+    m, n_q = 5, 9
+    th = [0.2, 0.3 * np.sqrt(D), 0.5]            # length scale grows with sqrt(D) so that the kernel does not vanish
+    X = orc.synthetic_design(n_q, D, m=m, seed=D)
+    N = X.shape[0]
+    S0 = orc.gram(X, th, kernel)
+    assert rel(host(eng.gram(X, th, kernel)), S0) < 1e-12
+    Xc = np.random.default_rng(D).random((130, D))
+    assert rel(host(eng.cross_cov(X, Xc, th, kernel)), orc.cross_cov(X, Xc, th, kernel)) < 1e-12
+    Sinv0 = orc.pd_inverse(S0)
+    f_init = np.random.default_rng(2).multivariate_normal(np.zeros(N), S0, method="cholesky")
+    f0, _ = orc.fit_fmap_trust_exact(f_init, Sinv0, m, th[0], gtol=1e-9)
+    Sinv = eng.pd_inverse(eng.gram(X, th, kernel))
+    post = eng.posterior(X, th, kernel, Sinv, f0, m)
+    P0 = orc.posterior_covariance(Sinv0, f0, m, th[0])
+    A0 = orc.variance_operator(Sinv0, P0, faithful=False, lam=orc.lambda_dense(f0, m, th[0]))
+    mu0, var0 = orc.predict_mean_var(Xc, X, th, Sinv0 @ f0, A0, kernel)
+    out = eng.predict(post, Xc)
+    assert rel(host(out["mu"]), mu0) < 1e-7
+    assert np.abs(host(out["var"]) - var0).max() <= 1e-7 * th[2] ** 2
+    mu_g, grad = eng.mean_grad(post, Xc[:17])
+    mu1, g1 = orc.mean_grad(Xc[:17], X, th, Sinv0 @ f0, kernel)
+    assert rel(host(mu_g), mu1) < 1e-7
+    assert np.abs(host(grad) - g1).max() <= 1e-7 * max(np.abs(g1).max(), 1e-12)
+    if kernel == "SE_kernel":
+        F = 70
+        W = np.random.default_rng(3).standard_normal((F, D)) / th[1]
+        b = np.random.default_rng(4).uniform(0, 2 * np.pi, F)
+        assert np.abs(host(eng.rff_project(X, W, b, th[2])) - orc.rff_features(X, W, b, th[2])).max() <= 1e-12
