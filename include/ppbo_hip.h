@@ -14,7 +14,10 @@
  *   - pointers named d_* are DEVICE pointers owned by the caller (row-major,
  *     C-contiguous float64 unless stated); h_* are HOST pointers.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
- *     Functions with host outputs synchronise that stream before returning.
+ *     Functions with host outputs synchronise that stream before returning.  Calls WITHOUT host outputs
+ *     (ppbo_gram, ppbo_cross_cov, ppbo_rff_project, ppbo_predict / ppbo_rff_score with NULL h_best_*, ...)
+ *     neither synchronise nor -- after their first call at a given size -- allocate, so a sequence of them can be
+ *     captured in a HIP graph on that stream and replayed (tests/test_gpu_concurrent.py).
  *   - a ppbo_ctx is bound to ONE device; every entry point runs on that device and restores
  *     the caller's current device on return.  Several contexts (on the same or different
  *     devices) may live in one process; a single ctx is not re-entrant across threads.

@@ -170,3 +170,49 @@ def test_contexts_on_two_devices_in_one_process(golden):
         assert np.array_equal(a, b)
     assert torch.cuda.current_device() == 0       # the library restored the caller's device every time
     e0.close(); e1.close()
+
+
+def test_entry_points_are_hip_graph_capture_safe(golden):
+    """Entry points without host outputs neither allocate (after their first call) nor synchronise, so a sequence of
+    them can be captured in a HIP graph on the caller's stream and replayed (bench.py times the short kernels that
+    way).  Replay must reproduce the direct calls bit for bit."""
+    import torch
+    from ppbo_amd.engine import get_engine, SCORE_POINTWISE_EI
+    from test_gpu_parity import _posterior
+    eng = get_engine(0)
+    g = golden("c2")
+    post, _ = _posterior(eng, g)
+    X, th, kern = eng.dev(g["X"]), g["theta"], str(g["kernel"])
+    N, D = X.shape
+    F = 256
+    W = eng.dev(np.random.default_rng(3).standard_normal((F, D)) / th[1])
+    b = eng.dev(np.random.default_rng(4).uniform(0, 2 * np.pi, F))
+    Xc = eng.dev(g["Xc"])
+    S_out, Phi_out = eng.empty(N, N), eng.empty(F, N)
+
+    def work():
+        eng.gram(X, th, kern, out=S_out)
+        eng.rff_project(X, W, b, th[2], out=Phi_out)
+        return eng.predict(post, Xc, score=SCORE_POINTWISE_EI, mustar=0.01, want_score=True, want_best=False)
+
+    ref = work()                                   # direct (also warms workspaces and LDS attributes)
+    ref = {k: (v.clone() if hasattr(v, "clone") else v) for k, v in ref.items()}
+    S_ref, Phi_ref = S_out.clone(), Phi_out.clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        work()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            out = work()
+    S_out.zero_(); Phi_out.zero_()
+    for k in ("mu", "var", "score"):
+        out[k].zero_()
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(S_out, S_ref) and torch.equal(Phi_out, Phi_ref)
+    for k in ("mu", "var", "score"):
+        assert torch.equal(out[k], ref[k])
