@@ -90,64 +90,39 @@ def _six_hump(v):
     return (4 - 2.1 * x ** 2 + x ** 4 / 3) * x ** 2 + x * y + (-4 + 4 * y ** 2) * y ** 2
 
 
-def _user(xi, x, lo, hi):
-    """Simulated user: the alpha maximising -f(alpha xi + x) inside the box (test_functions.py:54-61 uses DE)."""
-    from ppbo_amd.misc import alpha_bounds
-    a0, a1 = alpha_bounds(xi, lo, hi)
-    al = np.linspace(a0, a1, 4001)
-    pts = al[:, None] * xi[None, :] + x[None, :]
-    return float(al[np.argmin(_six_hump(pts))])
-
-
 def test_six_hump_camel_loop_c1():
-    """BASELINE config 1: D=2, 4 corner initial queries + 21 PCD queries, m=25 (ppbo_numerical_main.py:57-144)."""
-    from ppbo_amd.acquisition import next_query
-    from ppbo_amd.gp_model import GPModel
+    """BASELINE config 1: D=2, 4 corner initial queries + 21 PCD queries, m=25 (ppbo_numerical_main.py:57-144), through
+    ppbo_amd.numerical_main.run_ppbo_loop -- the reference's loop, flags and order on the drop-in classes."""
     from ppbo_amd.misc import hypercube_corners
+    from ppbo_amd.numerical_main import line_search_user, run_ppbo_loop
     from ppbo_amd.ppbo_settings import PPBO_settings
     np.random.seed(0)
     bounds = ((-3, 3), (-2, 2))
     lo, hi = np.array([-3.0, -2.0]), np.array([3.0, 2.0])
     st = PPBO_settings(D=2, bounds=bounds, xi_acquisition_function="PCD", m=25, theta_initial=[0.01, 0.26, 0.1],
                        verbose=False)
-    xis = np.tile(np.diag(hi), (2, 1))
-    xs = hypercube_corners(bounds)[:4].astype(float)
-    results = np.empty((0, 5))
-    gp = None
-    n_actual = 21
-    for i in range(4):
-        if i == 3:
-            gp.turn_initialization_off()
-        xi, x = xis[i].copy(), xs[i].copy()
-        x[xi != 0] = 0
-        a = _user(xi, x, lo, hi)
-        results = np.vstack([results, np.concatenate([a * xi + x, xi, [a]])])
-        if gp is None:
-            gp = GPModel(st)
-        gp.update_feedback_processing_object(results)
-        gp.update_data()
-        gp.update_model()
-    gp.turn_initialization_off()
-    Ns, mustars = [], []
-    for i in range(n_actual):
-        if i + 1 == n_actual:
-            gp.set_last_iteration()
-        xi, x = next_query(st, gp, unscale=True)
-        assert np.count_nonzero(xi) == 1                      # PCD: coordinate directions
-        a = _user(xi, x, lo, hi)
-        results = np.vstack([results, np.concatenate([a * xi + x, xi, [a]])])
-        gp.update_feedback_processing_object(results)
-        gp.mustar_previous_iteration = gp.mustar
-        gp.update_data()
-        gp.update_model()
+    xis = np.tile(np.diag(hi), (2, 1))                          # :136-139
+    xs = hypercube_corners(bounds)[:4].astype(float)           # :140
+    Ns, flags = [], []
+
+    def spy(k, gp):
         Ns.append(gp.N)
-        mustars.append(gp.mustar)
-    assert Ns[-1] == 25 * 26
-    xstar = gp.FP.unscale(gp.xstar)
+        flags.append((gp.initialization_running, gp.last_iteration))
+
+    results, xstars, mustars, gp = run_ppbo_loop(line_search_user(_six_hump, lo, hi), xis, xs, 21, st, callback=spy)
+    assert results.shape == (25, 5) and xstars.shape == (25, 2) and len(mustars) == 25
+    assert Ns == [26 * (k + 1) for k in range(25)]
+    assert [f[0] for f in flags] == [True, True, True] + [False] * 22     # initialisation off before the 4th update (:76-77)
+    assert not any(f[1] for f in flags)                                   # :104 never fires with initial queries
+    for k in range(4, 25):                                                # PCD: coordinate directions, cycling (:233-237)
+        xi = results[k, 2:4]
+        assert np.count_nonzero(xi) == 1 and np.argmax(np.abs(xi)) == (k - 4) % 2
+        assert np.allclose(results[k, :2], results[k, 4] * xi + np.where(xi != 0, 0.0, results[k, :2]))
+    assert np.array_equal(xstars[-1], gp.FP.unscale(gp.xstar)) and mustars[-1] == gp.mustar
     opt = np.array([[0.0898, -0.7126], [-0.0898, 0.7126]])
-    dist = np.min(np.linalg.norm(opt - xstar[None, :], axis=1))
-    assert dist <= 0.2, f"final x* {xstar} is {dist:.3f} from the optimum (reference run: 0.065)"
-    assert _six_hump(xstar) <= -0.9
+    dist = np.min(np.linalg.norm(opt - xstars[-1][None, :], axis=1))
+    assert dist <= 0.15, f"final x* {xstars[-1]} is {dist:.3f} from the optimum (reference run: 0.072)"
+    assert _six_hump(xstars[-1]) <= -0.9
 
 
 @pytest.mark.parametrize("acq", ["EXT", "RAND", "EI-EXT-FAST", "EI-EXT", "EI", "EXR", "EI-VARMAX-FAST"])
