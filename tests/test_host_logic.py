@@ -167,3 +167,58 @@ def test_tgn_sampler_follows_the_reference_density():
         assert s.min() >= a and s.max() <= b
         cdf = lambda v: (dist.cdf(v) - dist.cdf(a)) / mass         # noqa: E731
         assert scipy.stats.kstest(s, cdf).pvalue > 1e-3
+
+
+def test_run_ppbo_loop_call_order_matches_the_reference(monkeypatch):
+    """ppbo_numerical_main.py:57-127 restated in ppbo_amd/numerical_main.py: the sequence of model calls (creation at the
+    first query, turn_initialization_off before the LAST initial query's update and again after the block,
+    mustar_previous_iteration, optimize_theta at the configured query, x zeroed on xi's support) -- checked on CPU
+    with a recording stand-in for GPModel."""
+    from ppbo_amd import numerical_main as nm
+    log = []
+
+    class FakeFP:
+        def unscale(self, v, retain_0_values=False):
+            return np.asarray(v, dtype=float)
+
+    class FakeModel:
+        def __init__(self, settings, engine=None, incremental=False):
+            log.append(("create", incremental))
+            self.D = settings.D
+            self.FP = FakeFP()
+            self.xstar = np.full(settings.D, 0.25)
+            self.mustar = 0.0
+            self.verbose = False
+            self.mustar_previous_iteration = None
+            self.n = 0
+        def turn_initialization_off(self): log.append(("init_off", self.n))
+        def set_last_iteration(self): log.append(("last", self.n))
+        def update_feedback_processing_object(self, X_obs): self.n = len(X_obs); log.append(("fp", self.n, X_obs[-1].copy()))
+        def update_data(self): log.append(("data", self.n))
+        def update_model(self, optimize_theta=False):
+            log.append(("model", self.n, bool(optimize_theta)))
+            self.mustar = float(self.n)
+
+    monkeypatch.setattr(nm, "GPModel", FakeModel)
+    D = 3
+    st = PPBO_settings(D=D, bounds=((0, 1),) * D, xi_acquisition_function="PCD", m=5, verbose=False)
+    xi0 = np.eye(D)
+    x0 = np.array([[0.1, 0.2, 0.3], [0.4, 0.5, 0.6], [0.7, 0.8, 0.9]])
+    res, xs, ms, gp = nm.run_ppbo_loop(lambda xi, x: 0.5, xi0, x0, 4, st, optimize_hyperparameters_after_actual_query_number=2)
+    kinds = [e[0] for e in log]
+    assert kinds[0] == "create" and kinds.count("create") == 1
+    # initial block: fp/data/model per query; init_off right before the third (last) initial update and after the block
+    assert [e for e in log if e[0] == "init_off"] == [("init_off", 2), ("init_off", 3)]
+    assert [e[1:] for e in log if e[0] == "model"] == [(1, False), (2, False), (3, False), (4, False), (5, True), (6, False), (7, False)]
+    assert not any(k == "last" for k in kinds)                       # :104 never fires with initial queries
+    # x is zeroed on xi's support and the stored row is [alpha*xi + x ; xi ; alpha]
+    assert np.allclose(res[0], [0.5, 0.2, 0.3, 1, 0, 0, 0.5]) and np.allclose(res[1], [0.4, 0.5, 0.6, 0, 1, 0, 0.5])
+    # actual queries: PCD directions cycle 1, 2, 3, 1 and x exploits the model's x* off the direction
+    assert [int(np.argmax(r[D:2 * D])) for r in res[3:]] == [0, 1, 2, 0]
+    assert np.allclose(res[3], [0.5, 0.25, 0.25, 1, 0, 0, 0.5])
+    assert gp.mustar_previous_iteration == 6.0                       # the model's mu* BEFORE the last update (:113)
+    assert res.shape == (7, 2 * D + 1) and xs.shape == (7, D) and ms == [1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0]
+    # adaptive initialisation (:74-75) copies the previous answer into the remaining initial x's
+    log.clear()
+    res2, *_ = nm.run_ppbo_loop(lambda xi, x: 0.5, xi0, x0.copy(), 0, st, adaptive_initialization=True)
+    assert np.allclose(res2[1], [0.5, 0.5, 0.3, 0, 1, 0, 0.5])       # x := previous chosen point (0.5, 0.2, 0.3), then its 2nd coord zeroed
