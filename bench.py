@@ -147,6 +147,10 @@ def main():
     scaling = args.scaling or scaling_default
     M_arg = args.candidates or m_default
 
+    # before anything touches HIP: the host driver only supports dmabuf IPC (RCCL needs it), rendezvous on loopback
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
     import torch
     import torch.distributed as dist
     from ppbo_amd.engine import Engine, SCORE_POINTWISE_EI
