@@ -13,7 +13,12 @@ in-memory shims as tools/make_golden.py, nothing copied).  They pin what round 1
                 Hsampler.return_xstar for the stored omega (random_fourier_sampler.py:143-176), evidence
                 (gp_model.py:278-319) at three thetas.
 
-usage: python tools/make_golden_r2.py g7 | tgn | extras smoke rq c2 c4 c3
+Reproducibility: everything is seeded, but differential evolution (mu_star, the simulated user of g7) follows the
+bits of its objective, and those depend on the BLAS summation order: the committed files were produced in the 8-core
+build container with the DEFAULT OpenBLAS thread count (two runs are bit-identical there; with OPENBLAS_NUM_THREADS=2
+c2_x's DE results move by 3e-3 in x*, 3e-6 in mu*).  The `augment-*` commands add keys to an existing file.
+
+usage: python tools/make_golden_r2.py g7 | tgn | extras smoke rq c2 c4 c3 | augment-rff-dim smoke c2 | augment-omega-map c2
 """
 from __future__ import annotations
 
