@@ -11,4 +11,6 @@ run sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU 
 run fetch FETCH_SIZE
 run write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 run grbm GRBM_GUI_ACTIVE
+# write path of the HBM-bound kernels (Gram, RFF): requests, in-flight level (average latency = LEVEL / WRREQ), credit stalls
+run wstall TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum
 ls $OUT/*/ 

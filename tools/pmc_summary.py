@@ -43,6 +43,17 @@ if "SQ_INSTS_MFMA" in q:
     if "TCC_HIT_sum" in q and "TCC_MISS_sum" in q:
         d["l2_hit_rate"] = q["TCC_HIT_sum"] / (q["TCC_HIT_sum"] + q["TCC_MISS_sum"])
     q["derived"] = d
+for key in ("gram_mfma", "rff_project", "kstar"):
+    k = out.get(key, {})
+    if k.get("TCC_EA0_WRREQ_sum"):
+        d = k.setdefault("derived", {})
+        d["avg_write_latency_cycles(LEVEL/WRREQ)"] = k["TCC_EA0_WRREQ_LEVEL_sum"] / k["TCC_EA0_WRREQ_sum"]
+        d["dram_credit_stall_cycles_per_write_request"] = k.get("TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum", 0.0) / k["TCC_EA0_WRREQ_sum"]
+        d["write_requests_64B_fraction"] = k.get("TCC_EA0_WRREQ_64B_sum", 0.0) / k["TCC_EA0_WRREQ_sum"]
+        if "WRITE_SIZE" in k:
+            d["write_bytes"] = k["WRITE_SIZE"] * 1024.0
+        if "FETCH_SIZE" in k:
+            d["fabric_read_bytes(FETCH_SIZE KB x1024 x2 gfx950 correction)"] = k["FETCH_SIZE"] * 1024.0 * 2.0
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 try:                                   # which kernel sources the counters belong to (bench.py compares it with the tree)
     from ppbo_amd.build import _digest
