@@ -198,10 +198,16 @@ def main():
         f_init = eng.dgemv(Ls, np.random.default_rng(2).standard_normal(N), lower=True)
         del Ls
         fit_start = "prior draw L z, z = default_rng(2) (the fixture's own start is a warm start)"
-    def fit_once():
+    def fit_once(whitened=True):
+        """Sigma, Sigma^-1 (+ the Cholesky factor), f_MAP from the stored start, Lambda_MAP / G: the work of
+        update_Sigma + update_Sigma_inv + update_fMAP(1 trial) + the posterior (src/gp_model.py:91-117).
+        whitened=False: the exact trust-region Newton on f alone (rounds 1-2's fit), timed beside it."""
         Sigma = eng.gram(Xd, th, kern)
-        Sinv = eng.pd_inverse(Sigma)
-        fmap, st = eng.fit_fmap(Sinv, f_init, m, th[0], gtol=1e-4)
+        if whitened:
+            Sinv, Lc = eng.pd_inverse_chol(Sigma)
+        else:
+            Sinv, Lc = eng.pd_inverse(Sigma), None
+        fmap, st = eng.fit_fmap(Sinv, f_init, m, th[0], gtol=1e-4, L=Lc)
         post = eng.posterior(Xd, th, kern, Sinv, fmap, m)
         return post, st
     post, st = fit_once()            # warm (allocates workspaces)
@@ -218,6 +224,16 @@ def main():
     torch.cuda.synchronize()
     potrf_ms, potrf_n = eng.profile_read("potrf")
     eng.profile(False)
+    # the same fit through the exact trust-region Newton on f alone (what rounds 1-2 shipped): how much the
+    # whitened search buys, on this box, in this run (rank 0 only; skipped beyond N = 2048 where it takes seconds)
+    tr_fit_ms, tr_st = None, None
+    if rank == 0 and N <= 2048:
+        fit_once(whitened=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, tr_st = fit_once(whitened=False)
+        torch.cuda.synchronize()
+        tr_fit_ms = (time.perf_counter() - t0) * 1e3
     def burst_ms(fn, reps=40):
         """Steady-state duration of one launch of a SHORT kernel (8-100 us).  100 launches are captured in a HIP graph
         (torch.cuda.CUDAGraph over the stream the C-ABI launches on) and the graph is replayed back to back for tens
@@ -300,8 +316,8 @@ def main():
     def step():
         out = eng.predict(post, Xc, score=SCORE_POINTWISE_EI, mustar=mustar, want_mu=False, want_var=False,
                           want_score=False, want_best=True)
-        gidx = out["best_idx"] + row_lo
-        return allgather_argmax(out["best_val"], gidx, device=coll_dev)
+        gidx = out["best_idx"] + row_lo if out["best_idx"] >= 0 else -1     # an empty shard must not alias a neighbour's row
+        return allgather_argmax(out["best_val"], gidx, device=coll_dev, engine=eng)
 
     for _ in range(args.warmup):
         step()
@@ -394,6 +410,10 @@ def main():
                                       + (" [TEST MODE: ranks share one GPU, gloo]" if share_gpu else "")},
             "gp_fit_ms": gp_fit_ms, "gp_fit_ms_runs": fit_runs, "gp_fit_start": fit_start, "gp_fit_iterations": st["iterations"],
             "gp_fit_cholesky": st["n_cholesky"],
+            "gp_fit_method": "whitened L-BFGS (z = L^-1 f) + trust-region finisher (ppbo_fit_fmap_whitened)",
+            "gp_fit_lbfgs": {"iterations": st["lbfgs_iterations"], "evals": st["lbfgs_evals"], "status": st["lbfgs_status"]},
+            "gp_fit_trust_region_only": None if tr_st is None else {
+                "ms": tr_fit_ms, "iterations": tr_st["iterations"], "cholesky": tr_st["n_cholesky"]},
             "gp_fit_breakdown": {"potrf_calls": potrf_n, "potrf_avg_ms": potrf_ms / max(potrf_n, 1),
                                  "potrf_total_ms": potrf_ms,
                                  "note": "factorizations incl. Sigma^-1 and the posterior; failed ones end early"},

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PPBO_ABI_VERSION 2
+#define PPBO_ABI_VERSION 3
 #define PPBO_ERR_NOT_PD 1001
 
 typedef struct ppbo_ctx ppbo_ctx;
@@ -90,6 +90,11 @@ int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int
 /* ppbo_pd_inverse that also hands out L^-1 (A = L L^T, full matrix, zeros above the diagonal); d_Linv may be NULL */
 int ppbo_pd_inverse_factors(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, double* d_Linv, int* h_info,
                             void* stream);
+/* ... and, when d_L is not NULL, the Cholesky factor itself: d_L[N,N], lower triangle = L, the strict upper triangle
+ * is a copy of A's and is never read by this library.  L is what ppbo_fit_fmap_whitened iterates with, and
+ * L z (ppbo_dgemv, lower = 1) is the prior draw of src/gp_model.py:374,381.  d_L and d_Linv may each be NULL. */
+int ppbo_pd_inverse_ex(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, double* d_L, double* d_Linv,
+                       int* h_info, void* stream);
 
 /* ---- f-4: the inverse after one query has been appended --------------------------------
  * FeedbackProcessing.update_X (src/feedback_processing.py:133-154) only ever APPENDS the m+1 rows of the
@@ -129,6 +134,7 @@ typedef struct ppbo_fit_opts {
   int maxiter;    /* <=0: 200*N like SciPy */
   int verbose;
   double initial_radius;   /* first trust radius; <= 0: SciPy's default 1.0 (what the reference runs with) */
+  int lbfgs_max_evals;     /* ppbo_fit_fmap_whitened: evaluation budget of the whitened pre-phase; <= 0: 4000 */
 } ppbo_fit_opts;
 typedef struct ppbo_fit_stats {
   int iterations;   /* outer trust-region iterations */
@@ -136,10 +142,29 @@ typedef struct ppbo_fit_stats {
   int converged;    /* 1 if |grad| < gtol */
   double T;         /* T(f_MAP) (src/gp_model.py:221-226) */
   double gradnorm;  /* |grad T(f_MAP)|_2 */
+  int lbfgs_iterations; /* ppbo_fit_fmap_whitened: accepted quasi-Newton steps of the whitened pre-phase (else 0) */
+  int lbfgs_evals;      /* ... its objective/gradient evaluations (each O(N^2): two products with L, one with Sigma^-1) */
+  int lbfgs_status;     /* ... how it ended: 1 |grad T| < gtol, 2 rounding floor, 3 line search failed, 4 non-finite
+                         * start, 5 budget spent; -1 when the pre-phase did not run */
 } ppbo_fit_stats;
 int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double sigma,
                   const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
                   ppbo_fit_stats* h_stats, void* stream);
+
+/* ---- a-8, the production path: the same minimiser found in the prior-whitened variable ------------------
+ * replaces the same call (src/gp_model.py:354-389, scipy trust-exact on f) for ONE start vector.
+ * With Sigma = L L^T (d_L from ppbo_pd_inverse_ex, row stride ldl) and f = L z,
+ *   -T(L z) = 1/2 |z|^2 + (1/m) sum_q sum_j Phi(Delta_qj / sqrt2)
+ * has the Hessian I - L^T Lambda L, free of cond(Sigma) ~ 1e7: a device-resident L-BFGS (history 8, Armijo /
+ * approximate-Wolfe acceptance) needs tens of O(N^2) evaluations where the trust-region Newton on f needs
+ * tens of O(N^3) factorizations.  It stops on the reference's own rule |grad_f T|_2 < gtol; whatever is left
+ * (a request below the rounding floor of the whitened iteration, a stalled line search) is finished by
+ * ppbo_fit_fmap from the point reached, so the result satisfies exactly what ppbo_fit_fmap's does.
+ * Same optimum as the reference on every golden fixture; the PATH (and hence, on a multi-modal posterior, which
+ * local maximum is found) is not SciPy's. */
+int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m,
+                           double sigma, const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
+                           ppbo_fit_stats* h_stats, void* stream);
 
 /* T(f) and grad T(f) for a given f (src/gp_model.py:221-240); h_T / d_grad may be NULL */
 int ppbo_T_and_grad(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_f, int N, int m,
@@ -251,6 +276,11 @@ int ppbo_dist_init(ppbo_ctx* ctx, const void* h_id128, int rank, int world);
 int ppbo_dist_destroy(ppbo_ctx* ctx);
 int ppbo_argmax_allgather(ppbo_ctx* ctx, double local_val, int64_t local_global_idx, double* h_best_val,
                           int64_t* h_best_idx, void* stream);
+/* the reduction alone, for callers that run the all-gather themselves (torch.distributed in ppbo_amd/dist.py):
+ * d_records[world][2] = (value, global index as a double) per rank, already gathered in device memory; one
+ * single-wavefront kernel applies the rule above and ONE 16-byte record is copied back. */
+int ppbo_argmax_combine(ppbo_ctx* ctx, const double* d_records, int world, double* h_best_val, int64_t* h_best_idx,
+                        void* stream);
 
 /* y = op(A) x for a square fp64 matrix; lower != 0 reads only the lower triangle (A is then
  * treated as lower-triangular).  Used for alpha = Sigma^-1 f_MAP (src/gp_model.py:445) and

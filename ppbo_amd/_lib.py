@@ -21,12 +21,14 @@ SCORE_MEAN, SCORE_POINTWISE_EI, SCORE_VARIANCE = 0, 1, 2
 
 
 class FitOpts(C.Structure):
-    _fields_ = [("gtol", C.c_double), ("maxiter", C.c_int), ("verbose", C.c_int), ("initial_radius", C.c_double)]
+    _fields_ = [("gtol", C.c_double), ("maxiter", C.c_int), ("verbose", C.c_int), ("initial_radius", C.c_double),
+                ("lbfgs_max_evals", C.c_int)]
 
 
 class FitStats(C.Structure):
     _fields_ = [("iterations", C.c_int), ("n_cholesky", C.c_int), ("converged", C.c_int),
-                ("T", C.c_double), ("gradnorm", C.c_double)]
+                ("T", C.c_double), ("gradnorm", C.c_double),
+                ("lbfgs_iterations", C.c_int), ("lbfgs_evals", C.c_int), ("lbfgs_status", C.c_int)]
 
 
 class Model(C.Structure):
@@ -52,9 +54,11 @@ SIGNATURES = {
     "ppbo_potrf": [_vp, _vp, _i, _i, C.POINTER(_i), _vp],
     "ppbo_pd_inverse": [_vp, _vp, _i, _vp, C.POINTER(_i), _vp],
     "ppbo_pd_inverse_factors": [_vp, _vp, _i, _vp, _vp, C.POINTER(_i), _vp],
+    "ppbo_pd_inverse_ex": [_vp, _vp, _i, _vp, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_pd_inverse_append": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_laplace_terms": [_vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp],
     "ppbo_fit_fmap": [_vp, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
+    "ppbo_fit_fmap_whitened": [_vp, _vp, _i, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
     "ppbo_T_and_grad": [_vp, _vp, _vp, _i, _i, _d, C.POINTER(_d), _vp, _vp],
     "ppbo_posterior": [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_predict": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _vp, _vp, _vp, C.POINTER(_d), C.POINTER(_i64), _vp],
@@ -71,11 +75,12 @@ SIGNATURES = {
     "ppbo_dist_init": [_vp, _vp, _i, _i],
     "ppbo_dist_destroy": [_vp],
     "ppbo_argmax_allgather": [_vp, _d, _i64, C.POINTER(_d), C.POINTER(_i64), _vp],
+    "ppbo_argmax_combine": [_vp, _vp, _i, C.POINTER(_d), C.POINTER(_i64), _vp],
     "ppbo_dgemm": [_vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i, _d, _vp, _i, _vp],
 }
 
 _lib = None
-ABI_VERSION = 2     # must equal PPBO_ABI_VERSION of include/ppbo_hip.h
+ABI_VERSION = 3     # must equal PPBO_ABI_VERSION of include/ppbo_hip.h
 
 
 def _check_stamp():

@@ -4,8 +4,9 @@ Monte-Carlo line acquisitions evaluated in batches on the GPU (ppbo_line_acq).
 EI / varmax of a projective query (xi, x): 70 noisy-equispaced grid points on the line
 (src/acquisition.py:72-81, 170-178), posterior mean + 70x70 covariance, S draws, max over the
 line.  The reference evaluates one line per Python call and searches (xi, x) with GPyOpt's
-Bayesian optimisation (25 evaluations); here B lines are scored per launch with common random
-numbers, and the outer search is a batched random search over the same domain.
+Bayesian optimisation (5 + BO_maxiter evaluations); here B lines are scored per launch with common
+random numbers, and the outer search is a batched evolutionary search over the same domain whose
+number of refinement rounds follows PPBO_settings.BO_maxiter (_batched_search).
 """
 from __future__ import annotations
 
@@ -14,15 +15,28 @@ import time
 import numpy as np
 
 LINE_POINTS = 70          # acquisition.py:73,171
-SEARCH_LINES = 256        # lines per batched outer search (the reference's BO spends 5 + BO_maxiter)
+SEARCH_LINES = 256        # lines of the first (uniform) round of an outer search
+REFINE_LINES = 64         # lines per refinement round
+REFINE_PARENTS = 8        # incumbents each refinement round perturbs
+# the reference's GPyOpt BO spends 5 initial + PPBO_settings.BO_maxiter sequential line evaluations on one search;
+# here BO_maxiter buys refinement rounds instead: one per 5 iterations of the reference's budget (20 -> 4 rounds)
+ITERS_PER_ROUND = 5
+# Monte-Carlo draws per line INSIDE an outer search = SEARCH_DRAW_FACTOR x PPBO_settings.mc_samples: at the
+# reference's 150 draws the estimator's noise (~11 % for varmax) exceeds the spread of the acquisition value over
+# the search domain, and a maximiser of the 150-draw estimate mostly maximises noise; a launch scores 512 lines x
+# 1200 draws in ~35 ms, where one 150-draw line costs the reference ~0.36 s.  EI() / varmax() themselves keep
+# mc_samples as given.
+SEARCH_DRAW_FACTOR = 8
 
 
-def _line_scores(xis, xs, GP_model, mc_samples):
-    """EI and varmax of B lines in one device call.  Grid noise and z come from the global NumPy stream."""
+def _line_scores(xis, xs, GP_model, mc_samples, z=None):
+    """EI and varmax of B lines in one device call.  Grid noise (and z unless given) come from the global NumPy
+    stream; a caller comparing lines passes ONE z so that every line sees the same draws (common random numbers)."""
     FP = GP_model.FP
     grids = np.stack([FP.xi_grid(xi=xi, x=x, alpha_grid_distribution="equispaced", alpha_star=None, m=LINE_POINTS,
                                  is_scaled=True) for xi, x in zip(xis, xs)])
-    z = np.random.standard_normal((mc_samples, LINE_POINTS))
+    if z is None:
+        z = np.random.standard_normal((mc_samples, LINE_POINTS))
     sf2 = float(GP_model.theta[2]) ** 2
     ei, vm = GP_model.eng.line_acq(GP_model._post, grids, z, GP_model.mustar, GP_model.COVARIANCE_SHRINKAGE,
                                    jitter=1e-10 * sf2)
@@ -45,19 +59,62 @@ def perturbate_zerocoordinates(x, coords):
     return x
 
 
+def refinement_rounds(PPBO_settings):
+    return int(np.ceil(max(int(getattr(PPBO_settings, "BO_maxiter", 20)), 0) / ITERS_PER_ROUND))
+
+
+def _batched_search(k, lines_of, GP_model, PPBO_settings, which):
+    """Maximise EI (which='ei') or varmax ('vm') over u in [0,1]^k, where lines_of(U[B,k]) -> (xis[B,D], xs[B,D]).
+    Replaces the GPyOpt Bayesian optimisation of src/acquisition.py:96-100,119-123,194-198,210-214 (GPyOpt==1.2.6
+    is not installable here): a batched evolutionary search that scores whole populations per device
+    launch -- SEARCH_LINES uniform draws, then refinement_rounds() rounds of REFINE_LINES Gaussian perturbations of
+    the REFINE_PARENTS best lines so far with a width that halves every round (0.2, 0.1, ... of the unit box) --
+    all with ONE set of SEARCH_DRAW_FACTOR x mc_samples Monte-Carlo draws, so lines are ranked by common random
+    numbers instead of by 150-draw noise; the best REFINE_PARENTS then meet in a play-off on fresh draws.
+    Returns the best u and a log [(round, best value so far)]."""
+    draws = SEARCH_DRAW_FACTOR * int(PPBO_settings.mc_samples)
+    z = np.random.standard_normal((draws, LINE_POINTS))
+    pick = 0 if which == "ei" else 1
+
+    def score(U, zz=z):
+        xis, xs = lines_of(U)
+        return _line_scores(xis, xs, GP_model, draws, z=zz)[pick]
+
+    U = np.random.uniform(0.0, 1.0, (SEARCH_LINES, k))
+    V = score(U)
+    log = [(0, float(V.max()))]
+    for rnd in range(1, refinement_rounds(PPBO_settings) + 1):
+        parents = U[np.argsort(-V)[:REFINE_PARENTS]]
+        width = 0.2 * 0.5 ** (rnd - 1)
+        kids = parents[np.arange(REFINE_LINES) % len(parents)] + width * np.random.standard_normal((REFINE_LINES, k))
+        kids = np.clip(kids, 0.0, 1.0)
+        U, V = np.vstack([U, kids]), np.concatenate([V, score(kids)])
+        log.append((rnd, float(V.max())))
+    # play-off: the incumbents' values are biased upwards by their own selection; the REFINE_PARENTS best are
+    # re-scored on an independent set of draws (and fresh grid noise) and the winner is chosen on those alone
+    finalists = U[np.argsort(-V)[:REFINE_PARENTS]]
+    V2 = score(finalists, np.random.standard_normal((draws, LINE_POINTS)))
+    return finalists[int(np.argmax(V2))], log
+
+
 def _search_joint(xi_dims, GP_model, PPBO_settings, which, fixed_x=None):
-    """Batched replacement of maximize_EI / maximize_EI_fixed_x / maximize_varmax
-    (src/acquisition.py:91-131, 189-206): xi free on xi_dims, x free on the complement."""
+    """maximize_EI / maximize_EI_fixed_x / maximize_varmax (src/acquisition.py:91-131, 189-206): xi free on xi_dims,
+    x free on the complement (or pinned to fixed_x there)."""
     D = GP_model.D
+    xi_dims = list(xi_dims)
     x_dims = [i for i in range(D) if i not in xi_dims]
-    U = np.random.uniform(0, 1, (SEARCH_LINES, D))
-    xis = np.zeros((SEARCH_LINES, D))
-    xs = np.zeros((SEARCH_LINES, D))
-    xis[:, xi_dims] = U[:, xi_dims]
-    xs[:, x_dims] = U[:, x_dims] if fixed_x is None else fixed_x[x_dims]
-    ei, vm = _line_scores(xis, xs, GP_model, PPBO_settings.mc_samples)
-    b = int(np.argmax(ei if which == "ei" else vm))
-    return perturbate_zerocoordinates(xis[b], xi_dims), perturbate_zerocoordinates(xs[b], x_dims)
+    free = xi_dims + ([] if fixed_x is not None else x_dims)
+
+    def lines_of(U):
+        xis, xs = np.zeros((len(U), D)), np.zeros((len(U), D))
+        xis[:, xi_dims] = U[:, :len(xi_dims)]
+        xs[:, x_dims] = U[:, len(xi_dims):] if fixed_x is None else np.asarray(fixed_x)[x_dims]
+        return xis, xs
+
+    u, log = _batched_search(len(free), lines_of, GP_model, PPBO_settings, which)
+    GP_model.acq_search_log = log
+    xis, xs = lines_of(u[None, :])
+    return perturbate_zerocoordinates(xis[0], xi_dims), perturbate_zerocoordinates(xs[0], x_dims)
 
 
 def maximize_EI(xi_dims, GP_model, PPBO_settings):
@@ -73,11 +130,21 @@ def maximize_varmax(xi_dims, GP_model, PPBO_settings):
 
 
 def maximize_varmax_given_xi(xi, GP_model, PPBO_settings):
+    """x maximising varmax for a given direction (src/acquisition.py:208-218); x is zero on xi's support."""
     D = GP_model.D
-    xs = np.random.uniform(0, 1, (SEARCH_LINES, D))
-    xs[:, np.where(np.asarray(xi) != 0)[0]] = 0.0
-    _, vm = _line_scores([xi] * SEARCH_LINES, xs, GP_model, PPBO_settings.mc_samples)
-    return xs[int(np.argmax(vm))]
+    xi = np.asarray(xi, dtype=float)
+    free = list(np.where(xi == 0)[0])
+    if not free:
+        return np.zeros(D)
+
+    def lines_of(U):
+        xs = np.zeros((len(U), D))
+        xs[:, free] = U
+        return np.tile(xi, (len(U), 1)), xs
+
+    u, log = _batched_search(len(free), lines_of, GP_model, PPBO_settings, "vm")
+    GP_model.acq_search_log = log
+    return lines_of(u[None, :])[1][0]
 
 
 def EId_xstar(GP_model, mc_samples):

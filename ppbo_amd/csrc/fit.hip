@@ -261,6 +261,273 @@ __global__ __launch_bounds__(1024) void restep_kernel(const double* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Whitened quasi-Newton pre-phase of the f_MAP search (ppbo_fit_fmap_whitened).
+//
+// With Sigma = L L^T and f = L z the objective phi(z) = -T(L z) = 1/2 |z|^2 + (1/m) sum Phi(Delta/sqrt2) has
+// the Hessian I - L^T Lambda L: cond(Sigma) ~ 1e7 (what forces the reference, and ppbo_fit_fmap, into an exact
+// trust-region Newton with one N^3/3 factorization per trial shift) is gone from it, and L-BFGS reaches the
+// optimum in tens of O(N^2) evaluations:  f = L z,  beta(f),  grad_z phi = z - L^T beta.
+// The whole recurrence is device-resident.  One SLOT = {f = L zt; Laplace terms; u = L^T beta; v = Sigma^-1 f
+// (gated); lbfgs_step_kernel}; the step kernel (ONE workgroup) judges the trial point, updates the pair history,
+// forms the next direction by the vector-free two-loop recursion on the Gram matrix of the basis
+// {s_0..s_{H-1}, y_0..y_{H-1}, g} and writes the next trial point.  The host enqueues several slots per
+// read-back; every kernel of a slot is gated on the state's status word, so the slots behind the one that
+// finishes are no-ops.  The stopping rule is the reference's own: |grad_f T|_2 = |Sigma^-1 f - beta| < gtol
+// (src/gp_model.py:382-384, SciPy's default gtol), evaluated only once |grad_z| is small enough for it to be
+// possible (|grad_f| >= |grad_z| / |L|_F).
+constexpr int LB_H = 8;                 // history pairs
+constexpr int LB_NB = 2 * LB_H + 1;     // basis vectors: s ring [0,H), y ring [H,2H), current gradient 2H
+constexpr int LB_T = 1024;              // threads of the step workgroup
+constexpr int LB_MAX_BACKTRACK = 12;
+
+struct WhState {
+  int status;      // 0 running, 1 converged (|grad_f| < gtol), 2 stagnated at the rounding floor, 3 line search
+                   // failed along steepest descent, 4 non-finite objective at the start, 5 evaluation budget spent
+  int evals, iters, hist, head, first, ls, stall, need_gf, max_evals;
+  double phi, dphi, alpha, gz2, gf2, gate, gtol2;
+  double B[LB_NB * LB_NB];
+};
+
+// rowsq[i] = sum_{k <= i} L[i][k]^2 (= Sigma_ii); their sum is |L|_F^2 >= lambda_max(Sigma)
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const double* __restrict__ L, int N, int ldl,
+                                                         double* __restrict__ rowsq) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const double* row = L + (size_t)i * ldl;
+  double s = 0.0;
+  for (int k = lane; k <= i; k += 64) s += row[k] * row[k];
+  s = wave_sum(s);
+  if (lane == 0) rowsq[i] = s;
+}
+
+__global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ st, const double* __restrict__ rowsq,
+                                                          int N, double gtol, int max_evals) {
+  __shared__ double sh[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < N; i += LB_T) s += rowsq[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    st->status = 0; st->evals = 0; st->iters = 0; st->hist = 0; st->head = 0; st->first = 1; st->ls = 0;
+    st->stall = 0; st->need_gf = 0; st->max_evals = max_evals;
+    st->phi = 0.0; st->dphi = 0.0; st->alpha = 0.0; st->gz2 = 0.0; st->gf2 = -1.0;
+    st->gate = gtol * sqrt(t);          // |grad_f| < gtol needs |grad_z| < gtol |L|_F
+    st->gtol2 = gtol * gtol;
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void lb_block_sum(double (&v)[K], double* __restrict__ red, double* __restrict__ out) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[w * K + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double t = 0.0;
+    for (int ww = 0; ww < LB_T / 64; ++ww) t += red[ww * K + threadIdx.x];
+    out[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// One judgement of the trial point zt (its products u = L^T beta(L zt), v = Sigma^-1 L zt and the per-query
+// likelihood sums tq are already in memory).  See the block comment above; tests/probes/whitened_lbfgs_proto.py is
+// the NumPy statement of the same recurrence.
+__global__ __launch_bounds__(LB_T) void lbfgs_step_kernel(WhState* __restrict__ st, int N, int m, int n_q,
+                                                          double* __restrict__ z, double* __restrict__ zt,
+                                                          double* __restrict__ d, const double* __restrict__ u,
+                                                          const double* __restrict__ v,
+                                                          const double* __restrict__ beta,
+                                                          const double* __restrict__ tq, double* __restrict__ basis) {
+  __shared__ double shB[LB_NB * LB_NB];
+  __shared__ double red[(LB_T / 64) * LB_NB];
+  __shared__ double out[LB_NB];
+  __shared__ double delta[LB_NB];
+  __shared__ double shs[4];
+  __shared__ int act[4];
+  if (st->status != 0) return;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < LB_NB * LB_NB; i += LB_T) shB[i] = st->B[i];
+  const int first = st->first, need_gf = st->need_gf;
+  double* gcur = basis + (size_t)(2 * LB_H) * N;
+  const double c1 = 1e-4, c2 = 0.9, eps_f = 1e-13;
+  // ---- pass 1: objective, squared gradient norms, curvature of the would-be pair, slope at the trial point
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};   // zz, tsum, gf2, sy, ss, yy, gt.d
+  for (int i = tid; i < N; i += LB_T) {
+    const double zi = zt[i], gt = zi - u[i];
+    acc[0] += zi * zi;
+    if (need_gf) { const double gf = v[i] - beta[i]; acc[2] += gf * gf; }
+    if (!first) {
+      const double s = zi - z[i], y = gt - gcur[i];
+      acc[3] += s * y; acc[4] += s * s; acc[5] += y * y; acc[6] += gt * d[i];
+    }
+  }
+  for (int q = tid; q < n_q; q += LB_T) acc[1] += tq[q];
+  lb_block_sum<7>(acc, red, out);
+  if (tid == 0) {
+    const double phi_t = 0.5 * out[0] + out[1] / (double)m;
+    const double phi = st->phi, dphi = st->dphi, alpha = st->alpha;
+    const int evals = st->evals + 1;
+    st->evals = evals;
+    int a = 1;           // 0 backtrack, 1 accept, 2 restart along steepest descent, 3 stop
+    int pair_ok = 0;
+    const bool finite = isfinite(phi_t);
+    if (!first) {
+      const double dphi_t = out[6];
+      const bool armijo = phi_t <= phi + c1 * alpha * dphi;
+      const bool approx_wolfe = phi_t <= phi + eps_f * fmax(1.0, fabs(phi)) && (2.0 * c1 - 1.0) * dphi >= dphi_t &&
+                                dphi_t >= c2 * dphi;
+      if (!(finite && (armijo || approx_wolfe))) a = 0;
+    } else if (!finite) {
+      st->status = 4;
+      a = 3;
+    }
+    if (a == 0) {
+      const int ls = st->ls + 1;
+      st->ls = ls;
+      if (evals >= st->max_evals) { st->status = 5; a = 3; }
+      else if (ls > LB_MAX_BACKTRACK) {
+        if (st->hist > 0) {            // forget the history, retry from the accepted point along -g
+          st->hist = 0; st->ls = 0;
+          const double gz2 = shB[(2 * LB_H) * LB_NB + 2 * LB_H];
+          st->dphi = -gz2;
+          st->alpha = fmin(1.0, 1.0 / sqrt(gz2));
+          shs[0] = st->alpha;
+          a = 2;
+        } else { st->status = 3; a = 3; }
+      } else {
+        double an = finite ? -dphi * alpha * alpha / (2.0 * (phi_t - phi - dphi * alpha)) : 0.0;
+        if (!(an >= 0.1 * alpha)) an = 0.1 * alpha;      // also catches NaN
+        if (an > 0.5 * alpha) an = 0.5 * alpha;
+        st->alpha = an;
+        shs[0] = an;
+      }
+    } else if (a == 1) {
+      if (!first) {
+        pair_ok = out[3] > 1e-10 * sqrt(out[4] * out[5]);
+        st->stall = (phi - phi_t <= 1e-14 * fmax(1.0, fabs(phi))) ? st->stall + 1 : 0;
+        st->iters += 1;
+      }
+      st->phi = phi_t;
+      st->ls = 0;
+      if (need_gf) st->gf2 = out[2];
+      shs[1] = need_gf ? out[2] : -1.0;
+    }
+    act[0] = a; act[1] = pair_ok; act[2] = st->head;
+  }
+  __syncthreads();
+  const int a = act[0];
+  if (a == 3) return;
+  if (a == 0) {                       // shorter step along the same direction
+    const double an = shs[0];
+    for (int i = tid; i < N; i += LB_T) zt[i] = z[i] + an * d[i];
+    return;
+  }
+  if (a == 2) {                       // steepest descent from the accepted point
+    const double an = shs[0];
+    for (int i = tid; i < N; i += LB_T) { const double di = -gcur[i]; d[i] = di; zt[i] = z[i] + an * di; }
+    return;
+  }
+  // ---- accepted: move, store the pair, refresh the Gram rows of what changed
+  const int pair_ok = act[1], r = act[2];
+  for (int i = tid; i < N; i += LB_T) {
+    const double zi = zt[i], gt = zi - u[i];
+    if (pair_ok) {
+      basis[(size_t)r * N + i] = zi - z[i];
+      basis[(size_t)(LB_H + r) * N + i] = gt - gcur[i];
+    }
+    gcur[i] = gt;
+    z[i] = zi;
+  }
+  // each thread reads back only elements it wrote itself: no barrier needed before the dots
+  for (int t = 0; t < 3; ++t) {
+    if (t < 2 && !pair_ok) continue;
+    const int tgt = (t == 0) ? r : (t == 1 ? LB_H + r : 2 * LB_H);
+    double dots[LB_NB];
+#pragma unroll
+    for (int l = 0; l < LB_NB; ++l) dots[l] = 0.0;
+    for (int i = tid; i < N; i += LB_T) {
+      const double x = basis[(size_t)tgt * N + i];
+#pragma unroll
+      for (int l = 0; l < LB_NB; ++l) dots[l] += basis[(size_t)l * N + i] * x;
+    }
+    lb_block_sum<LB_NB>(dots, red, out);
+    if (tid < LB_NB) { shB[tgt * LB_NB + tid] = out[tid]; shB[tid * LB_NB + tgt] = out[tid]; }
+    __syncthreads();
+  }
+  // ---- stopping tests and the next direction (scalar work on the Gram matrix)
+  if (tid == 0) {
+    int hist = st->hist, head = st->head;
+    if (pair_ok) { head = (head + 1) % LB_H; hist = hist < LB_H ? hist + 1 : LB_H; }
+    const double gz2 = shB[(2 * LB_H) * LB_NB + 2 * LB_H];
+    st->gz2 = gz2;
+    int stop = 0;
+    if (shs[1] >= 0.0 && shs[1] < st->gtol2) { st->status = 1; stop = 1; }
+    else if (st->stall >= 3) { st->status = 2; stop = 1; }
+    else if (st->evals >= st->max_evals) { st->status = 5; stop = 1; }
+    else if (!(gz2 > 0.0)) { st->status = isfinite(gz2) ? 1 : 4; stop = 1; }
+    st->need_gf = sqrt(gz2) < st->gate;
+    for (int l = 0; l < LB_NB; ++l) delta[l] = 0.0;
+    double dphi = 0.0;
+    if (!stop) {
+      double al[LB_H];
+      delta[2 * LB_H] = -1.0;
+      for (int k = hist - 1; k >= 0; --k) {               // newest to oldest
+        const int rr = (head - hist + k + 2 * LB_H) % LB_H;
+        double t = 0.0;
+        for (int l = 0; l < LB_NB; ++l) t += delta[l] * shB[l * LB_NB + rr];
+        t /= shB[rr * LB_NB + LB_H + rr];
+        al[k] = t;
+        delta[LB_H + rr] -= t;
+      }
+      if (hist > 0) {
+        const int rn = (head - 1 + LB_H) % LB_H;
+        const double gam = shB[rn * LB_NB + LB_H + rn] / shB[(LB_H + rn) * LB_NB + LB_H + rn];
+        for (int l = 0; l < LB_NB; ++l) delta[l] *= gam;
+      }
+      for (int k = 0; k < hist; ++k) {                    // oldest to newest
+        const int rr = (head - hist + k + 2 * LB_H) % LB_H;
+        double t = 0.0;
+        for (int l = 0; l < LB_NB; ++l) t += delta[l] * shB[l * LB_NB + LB_H + rr];
+        t /= shB[rr * LB_NB + LB_H + rr];
+        delta[rr] += al[k] - t;
+      }
+      for (int l = 0; l < LB_NB; ++l) dphi += delta[l] * shB[l * LB_NB + 2 * LB_H];
+      if (!(dphi < 0.0)) {                                // not a descent direction: drop the history
+        hist = 0;
+        for (int l = 0; l < LB_NB; ++l) delta[l] = 0.0;
+        delta[2 * LB_H] = -1.0;
+        dphi = -gz2;
+      }
+      st->dphi = dphi;
+      st->alpha = first ? fmin(1.0, 1.0 / sqrt(gz2)) : 1.0;
+      shs[0] = st->alpha;
+    }
+    st->hist = hist; st->head = head; st->first = 0;
+    act[3] = stop;
+  }
+  __syncthreads();
+  for (int i = tid; i < LB_NB * LB_NB; i += LB_T) st->B[i] = shB[i];
+  if (act[3]) return;
+  const double an = shs[0];
+  for (int i = tid; i < N; i += LB_T) {
+    double di = 0.0;
+#pragma unroll
+    for (int l = 0; l < LB_NB; ++l) di += delta[l] * basis[(size_t)l * N + i];
+    d[i] = di;
+    zt[i] = z[i] + an * di;
+  }
+}
+
 struct FitWork {
   ppbo_ctx* ctx;
   hipStream_t s;
@@ -578,7 +845,13 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
     if (int rc = eval_point(W, T, W.p, C.v)) return rc;
     // phi(f) - phi(f+p) = -1/2 p'(Sf + S(f+p)) + (Tlik(f+p) - Tlik(f)), from small quantities
     const double actual = -0.5 * T.pv + (T.Tlik - C.Tlik);
-    const double rho = actual / pred;
+    double rho = actual / pred;
+    // Next to the optimum the predicted decrease drops below the rounding noise of the objective difference
+    // (~1e-13 at phi ~ 10: the likelihood is a sum of N terms), rho is then a random number and a perfectly good
+    // Newton step would be rejected and the radius quartered until it cuts the step (seen when the fit is
+    // started from the whitened pre-phase's result with a gtol below that phase's floor): there the step is
+    // judged by what it does to the gradient instead.
+    if (pred < 1e-11 * std::fmax(1.0, std::fabs(phi_of(C))) && T.gn2 < C.gn2) rho = 1.0;
     const double old_radius = radius;
     if (!(rho >= 0.25)) { if (!chord) radius *= 0.25; }   // a poor chord step blames the stale Hessian, not the radius
     else if (rho > 0.75 && boundary) radius = std::fmin(2.0 * radius, rmax);
@@ -598,6 +871,7 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
   PPBO_HIP_CHECK(ctx, hipMemcpyAsync(d_fMAP, pt[cur].f, vbytes, hipMemcpyDeviceToDevice, s));
   PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
   if (h_stats) {
+    h_stats->lbfgs_iterations = 0; h_stats->lbfgs_evals = 0; h_stats->lbfgs_status = -1;
     h_stats->iterations = it;
     h_stats->n_cholesky = nchol;
     h_stats->gradnorm = std::sqrt(pt[cur].gn2);
@@ -605,6 +879,77 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
     h_stats->T = -phi_of(pt[cur]);
   }
   return 0;
+}
+
+int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m,
+                           double sigma, const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
+                           ppbo_fit_stats* h_stats, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_L && d_Sigma_inv && d_f_init && d_fMAP, "null pointer");
+  PPBO_REQUIRE(ctx, N > 0 && ldl >= N && m >= 1 && sigma > 0, "sizes");
+  PPBO_REQUIRE(ctx, N % (m + 1) == 0, "N must be n_q*(m+1)");
+  hipStream_t s = (hipStream_t)stream;
+  const double gtol = (opts && opts->gtol > 0) ? opts->gtol : 1e-4;
+  const int verbose = opts ? opts->verbose : 0;
+  const int max_evals = (opts && opts->lbfgs_max_evals > 0) ? opts->lbfgs_max_evals : 4000;
+  const int mblk = m + 1, n_q = N / mblk;
+  // workspace: state | basis [LB_NB][N] | z zt d u v beta ft rowsq | tq
+  const size_t st_doubles = (sizeof(WhState) + 7) / 8 + 8;
+  const size_t nvec = (size_t)LB_NB + 8;
+  double* base = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LBFGS, (st_doubles + nvec * N + n_q + 64) * sizeof(double));
+  if (!base) return (int)hipErrorOutOfMemory;
+  WhState* st = (WhState*)base;
+  double* basis = base + st_doubles;
+  double* z = basis + (size_t)LB_NB * N;
+  double *zt = z + N, *dd = zt + N, *u = dd + N, *v = u + N, *beta = v + N, *ft = beta + N, *rowsq = ft + N;
+  double* tq = rowsq + N;
+  WhState* hst = (WhState*)ppbo_pinned(ctx, sizeof(WhState) + 64 * sizeof(double));
+  if (!hst) return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "pinned staging");
+  const size_t head_bytes = offsetof(WhState, B);
+  PPBO_HIP_CHECK(ctx, hipMemsetAsync(base, 0, (st_doubles + (size_t)LB_NB * N) * sizeof(double), s));
+  row_sqnorm_kernel<<<(N + 3) / 4, 256, 0, s>>>(d_L, N, ldl, rowsq);
+  lbfgs_init_kernel<<<1, LB_T, 0, s>>>(st, rowsq, N, gtol, max_evals);
+  PPBO_LAUNCH_CHECK(ctx);
+  // z0 = L^-1 f_init = L^T (Sigma^-1 f_init)
+  if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, d_f_init, v, 0, 0, s)) return rc;
+  if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, v, zt, 1, 1, s)) return rc;
+  PpboGate run; run.skip_if_nonzero = &st->status;
+  PpboGate run_gf = run; run_gf.skip_if_zero = &st->need_gf;
+  int batch = 4;
+  for (;;) {
+    for (int k = 0; k < batch; ++k) {
+      if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, zt, ft, 0, 1, s, run)) return rc;                  // f = L zt
+      laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(ft, N, mblk, n_q, sigma, tq, beta, nullptr, nullptr);
+      if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, beta, u, 1, 1, s, run)) return rc;                 // u = L^T beta
+      if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, ft, v, 0, 0, s, run_gf)) return rc;          // v = Sigma^-1 f
+      lbfgs_step_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, v, beta, tq, basis);
+    }
+    PPBO_LAUNCH_CHECK(ctx);
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(hst, st, head_bytes, hipMemcpyDeviceToHost, s));
+    PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    if (verbose)
+      printf("[ppbo_fit whitened] evals %d iters %d phi %.12e |grad_z| %.3e |grad_f| %.3e status %d\n", hst->evals,
+             hst->iters, hst->phi, std::sqrt(hst->gz2), hst->gf2 >= 0 ? std::sqrt(hst->gf2) : -1.0, hst->status);
+    if (hst->status != 0) break;
+    if (batch < 8) batch = 8;
+  }
+  const int lb_status = hst->status, lb_iters = hst->iters, lb_evals = hst->evals;
+  if (lb_status == 4) {
+    // the start vector has no finite objective in whitened form: leave everything to the trust region
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(d_fMAP, d_f_init, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+  } else {
+    if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, z, d_fMAP, 0, 1, s)) return rc;                      // f = L z
+  }
+  // finisher: the exact trust-region Newton from there (no iteration at all when |grad_f| < gtol already holds)
+  ppbo_fit_stats tr{};
+  const int rc = ppbo_fit_fmap(ctx, d_Sigma_inv, N, m, sigma, d_fMAP, opts, d_fMAP, &tr, stream);
+  if (h_stats) {
+    *h_stats = tr;
+    h_stats->lbfgs_iterations = lb_iters;
+    h_stats->lbfgs_evals = lb_evals;
+    h_stats->lbfgs_status = lb_status;
+  }
+  return rc;
 }
 
 int ppbo_posterior(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fMAP, int N, int m, double sigma,

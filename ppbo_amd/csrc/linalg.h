@@ -36,8 +36,21 @@ int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d
                      int skip_top = 0, int* split_out = nullptr);
 int ppbo_apply_linv_async(ppbo_ctx* ctx, const double* d_Linv, int ldi, const double* d_L, int ldl, int N, int split,
                           const double* d_x, double* d_y, int trans, double* d_tmp, hipStream_t s);
+// Device-side gate of a launch: the kernel returns at once when *skip_if_nonzero != 0 or *skip_if_zero == 0
+// (null pointers = no condition).  Lets the host enqueue a fixed sequence of launches whose tail turns into
+// no-ops once a device-resident iteration has decided that it is finished (csrc/fit.hip, whitened L-BFGS).
+struct PpboGate {
+  const int* skip_if_nonzero = nullptr;
+  const int* skip_if_zero = nullptr;
+#ifdef __HIPCC__
+  __device__ __forceinline__ bool closed() const {
+    return (skip_if_nonzero && *skip_if_nonzero != 0) || (skip_if_zero && *skip_if_zero == 0);
+  }
+#endif
+};
+
 // y = T x (trans=0) or y = T^T x (trans=1) for a lower-triangular (lower=1) or full N x N matrix
 int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const double* d_x, double* d_y, int trans,
-                    int lower, hipStream_t s);
+                    int lower, hipStream_t s, PpboGate gate = PpboGate());
 // out[0] = sum_i x_i y_i  (deterministic single-block reduction)
 int ppbo_dot_async(ppbo_ctx* ctx, const double* d_x, const double* d_y, int N, double* d_out, hipStream_t s);

@@ -721,7 +721,8 @@ __global__ __launch_bounds__(256) void trtri_diag_kernel(const double* __restric
 // y = T x, one wavefront per row
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ T, int rows, int cols, int ldt,
                                                         const double* __restrict__ x, const double* __restrict__ y0,
-                                                        double* __restrict__ y, int lower) {
+                                                        double* __restrict__ y, int lower, PpboGate gate) {
+  if (gate.closed()) return;
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= rows) return;
@@ -753,7 +754,8 @@ constexpr int GT_ROWS = 16;
 
 __global__ __launch_bounds__(256) void gemvT_partial_kernel(const double* __restrict__ T, int rows, int cols, int ldt,
                                                             const double* __restrict__ x,
-                                                            double* __restrict__ partial, int lower) {
+                                                            double* __restrict__ partial, int lower, PpboGate gate) {
+  if (gate.closed()) return;
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int i0 = blockIdx.y * GT_ROWS;
   if (lower && i0 + GT_ROWS <= (int)blockIdx.x * 256) return;      // no row of this split reaches these columns
@@ -773,7 +775,8 @@ __global__ __launch_bounds__(256) void gemvT_partial_kernel(const double* __rest
 // y[j] = sum over the splits that were written; 16 columns x 16 split groups per workgroup, fixed summation order
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const double* __restrict__ partial, int n_split, int N,
                                                         const double* __restrict__ y0, double* __restrict__ y,
-                                                        int lower) {
+                                                        int lower, PpboGate gate) {
+  if (gate.closed()) return;
   __shared__ double sh[16][17];
   const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + c;
@@ -955,23 +958,24 @@ int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d
 
 // y = T x (trans = 0, T rows x cols) or y = T^T x (trans = 1); with y0: y = y0 - (that product)
 int ppbo_gemv_rect_async(ppbo_ctx* ctx, const double* d_T, int rows, int cols, int ldt, const double* d_x,
-                         const double* d_y0, double* d_y, int trans, int lower, hipStream_t s) {
+                         const double* d_y0, double* d_y, int trans, int lower, hipStream_t s,
+                         PpboGate gate = PpboGate()) {
   if (!trans) {
-    gemv_rows_kernel<<<(rows + 3) / 4, 256, 0, s>>>(d_T, rows, cols, ldt, d_x, d_y0, d_y, lower);
+    gemv_rows_kernel<<<(rows + 3) / 4, 256, 0, s>>>(d_T, rows, cols, ldt, d_x, d_y0, d_y, lower, gate);
   } else {
     const int n_split = (rows + GT_ROWS - 1) / GT_ROWS;
     double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, (size_t)n_split * cols * sizeof(double));
     if (!part) return (int)hipErrorOutOfMemory;
-    gemvT_partial_kernel<<<dim3((cols + 255) / 256, n_split), 256, 0, s>>>(d_T, rows, cols, ldt, d_x, part, lower);
-    sum_slabs_kernel<<<(cols + 15) / 16, 256, 0, s>>>(part, n_split, cols, d_y0, d_y, lower);
+    gemvT_partial_kernel<<<dim3((cols + 255) / 256, n_split), 256, 0, s>>>(d_T, rows, cols, ldt, d_x, part, lower, gate);
+    sum_slabs_kernel<<<(cols + 15) / 16, 256, 0, s>>>(part, n_split, cols, d_y0, d_y, lower, gate);
   }
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
 
 int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const double* d_x, double* d_y, int trans,
-                    int lower, hipStream_t s) {
-  return ppbo_gemv_rect_async(ctx, d_T, N, N, ldt, d_x, nullptr, d_y, trans, lower, s);
+                    int lower, hipStream_t s, PpboGate gate) {
+  return ppbo_gemv_rect_async(ctx, d_T, N, N, ldt, d_x, nullptr, d_y, trans, lower, s, gate);
 }
 
 // y = L^-1 x / y = L^-T x with the inverse held as ppbo_trtri_async(skip_top = 1) leaves it: the two diagonal
@@ -1078,15 +1082,17 @@ int ppbo_pd_inverse_append(ppbo_ctx* ctx, const double* d_A, int N, const double
   return 0;
 }
 
-int ppbo_pd_inverse_factors(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, double* d_Linv, int* h_info,
-                            void* stream) {
+int ppbo_pd_inverse_ex(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, double* d_L, double* d_Linv,
+                       int* h_info, void* stream) {
   PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_A && d_Ainv && N > 0, "matrix");
+  PPBO_REQUIRE(ctx, d_L != d_A && d_L != d_Ainv && d_Linv != d_Ainv, "outputs must not alias");
   hipStream_t s = (hipStream_t)stream;
   const size_t bytes = (size_t)N * N * sizeof(double);
-  double* L = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG, 2 * bytes);
-  if (!L) return (int)hipErrorOutOfMemory;
-  double* Li = d_Linv ? d_Linv : L + (size_t)N * N;
+  double* W = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG, 2 * bytes);
+  if (!W) return (int)hipErrorOutOfMemory;
+  double* L = d_L ? d_L : W;                 // factor straight into the caller's buffer when it wants the factor
+  double* Li = d_Linv ? d_Linv : W + (size_t)N * N;
   PPBO_HIP_CHECK(ctx, hipMemcpyAsync(L, d_A, bytes, hipMemcpyDeviceToDevice, s));
   int info = 0;
   if (int rc = ppbo_potrf(ctx, L, N, N, &info, stream)) {
@@ -1101,8 +1107,13 @@ int ppbo_pd_inverse_factors(ppbo_ctx* ctx, const double* d_A, int N, double* d_A
   return ppbo_gemm_launch(ctx, g, 1, 0, s);
 }
 
+int ppbo_pd_inverse_factors(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, double* d_Linv, int* h_info,
+                            void* stream) {
+  return ppbo_pd_inverse_ex(ctx, d_A, N, d_Ainv, nullptr, d_Linv, h_info, stream);
+}
+
 int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int* h_info, void* stream) {
-  return ppbo_pd_inverse_factors(ctx, d_A, N, d_Ainv, nullptr, h_info, stream);
+  return ppbo_pd_inverse_ex(ctx, d_A, N, d_Ainv, nullptr, nullptr, h_info, stream);
 }
 
 }  // extern "C"

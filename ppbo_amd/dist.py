@@ -32,9 +32,11 @@ def combine_best(vals: torch.Tensor, idxs: torch.Tensor):
     return (best_v if best_i >= 0 else float("nan")), best_i
 
 
-def allgather_argmax(local_val: float, local_global_idx: int, device=None, group=None):
+def allgather_argmax(local_val: float, local_global_idx: int, device=None, group=None, engine=None):
     """All ranks get the global (value, index) from ONE all-gather of a 16-byte record per rank.
-    The index travels as a float64 (exact below 2**53)."""
+    The index travels as a float64 (exact below 2**53).  With an `engine` and device tensors (the RCCL path) the
+    gathered records are reduced on the device (ppbo_argmax_combine: one wavefront) and one 16-byte record is
+    read back; on host tensors (gloo, the CPU tests) combine_best applies the same rule."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return float(local_val), int(local_global_idx)
     world = dist.get_world_size(group)
@@ -42,6 +44,8 @@ def allgather_argmax(local_val: float, local_global_idx: int, device=None, group
     rec = torch.tensor([float(local_val), float(local_global_idx)], dtype=torch.float64, device=dev)
     out = torch.empty(2 * world, dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(out, rec, group=group)
+    if engine is not None and out.is_cuda:
+        return engine.argmax_combine(out)
     out = out.cpu().view(world, 2)
     return combine_best(out[:, 0], out[:, 1].to(torch.int64))
 
@@ -51,7 +55,7 @@ def sharded_search(engine, post, Xc_shard, shard_offset: int, score, mustar=0.0,
     out = engine.predict(post, Xc_shard, score=score, mustar=mustar, want_mu=False, want_var=False,
                          want_score=False, want_best=True)
     gidx = out["best_idx"] + shard_offset if out["best_idx"] >= 0 else -1
-    return allgather_argmax(out["best_val"], gidx, device=engine.device, group=group)
+    return allgather_argmax(out["best_val"], gidx, device=engine.device, group=group, engine=engine)
 
 
 def rank_world(group=None):
@@ -76,3 +80,19 @@ def allgather_strided(local_vals, n_total: int, device=None, group=None):
     dist.all_gather_into_tensor(out, rec, group=group)
     out = out.cpu().view(world, per)
     return [float(out[k % world, k // world]) for k in range(n_total)]
+
+
+def assert_same_across_ranks(values, what: str, device=None, group=None):
+    """Raise on every rank if `values` (a short list of floats, e.g. a checksum of inputs every rank is supposed to
+    have generated identically from the same seed) differ between ranks; one all-gather."""
+    rank, world = rank_world(group)
+    if world == 1:
+        return
+    dev = device if device is not None else torch.device("cpu")
+    rec = torch.as_tensor([float(v) for v in values], dtype=torch.float64).to(dev)
+    out = torch.empty(world * rec.numel(), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, rec, group=group)
+    out = out.cpu().view(world, -1)
+    if not bool((out == out[0:1]).all()):
+        raise RuntimeError(f"{what} differ between ranks (rank {rank} sees {out.tolist()}): every rank must draw them "
+                           "from an identically seeded NumPy stream, or receive them from rank 0")

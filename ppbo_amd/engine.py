@@ -121,6 +121,15 @@ class Engine:
         self._check(rc, "ppbo_argmax_allgather")
         return bv.value, bi.value
 
+    def argmax_combine(self, records):
+        """records: device float64 [world, 2] of (value, global index) -> (best value, its index); reduced on the
+        device by one wavefront, one 16-byte read-back."""
+        bv, bi = C.c_double(0.0), C.c_int64(-1)
+        rc = self.lib.ppbo_argmax_combine(self.ctx, _ptr(records), int(records.numel() // 2), C.byref(bv), C.byref(bi),
+                                          self._stream())
+        self._check(rc, "ppbo_argmax_combine")
+        return bv.value, bi.value
+
     # ---- per-kernel event timing ---------------------------------------------
     def profile(self, on=True):
         self.lib.ppbo_profile_enable(self.ctx, int(on))
@@ -182,6 +191,16 @@ class Engine:
         rc = self.lib.ppbo_pd_inverse_factors(self.ctx, _ptr(A), N, _ptr(out), _ptr(linv), C.byref(info), self._stream())
         self._check(rc, "ppbo_pd_inverse_factors", info.value)
         return out, linv
+
+    def pd_inverse_chol(self, A):
+        """(A^-1, L) with A = L L^T (lower triangle of L valid): what fit_fmap_whitened iterates with."""
+        A = self.dev(A)
+        N = A.shape[0]
+        out, L = self.empty(N, N), self.empty(N, N)
+        info = C.c_int(0)
+        rc = self.lib.ppbo_pd_inverse_ex(self.ctx, _ptr(A), N, _ptr(out), _ptr(L), None, C.byref(info), self._stream())
+        self._check(rc, "ppbo_pd_inverse_ex", info.value)
+        return out, L
 
     def pd_inverse_append(self, A, A11inv, L11inv):
         """(A^-1, L^-1) of A[N,N] given those of its leading N1 x N1 block (one appended query, f-4)."""
@@ -252,17 +271,27 @@ class Engine:
         self._check(rc, "ppbo_T_and_grad")
         return T.value, grad
 
-    def fit_fmap(self, Sigma_inv, f_init, m, sigma, gtol=1e-4, maxiter=0, verbose=False, initial_radius=0.0):
+    def fit_fmap(self, Sigma_inv, f_init, m, sigma, gtol=1e-4, maxiter=0, verbose=False, initial_radius=0.0, L=None,
+                 lbfgs_max_evals=0):
+        """f_MAP from one start vector.  L = None: trust-region Newton on f (ppbo_fit_fmap, the reference's
+        algorithm class); L = Cholesky factor of Sigma: whitened L-BFGS finished by that trust region
+        (ppbo_fit_fmap_whitened) -- same optimum, tens of O(N^2) evaluations instead of O(N^3) factorizations."""
         f0 = self.dev(f_init).reshape(-1)
         N = f0.numel()
         out = self.empty(N)
-        opts = _lib.FitOpts(float(gtol), int(maxiter), int(verbose), float(initial_radius))
+        opts = _lib.FitOpts(float(gtol), int(maxiter), int(verbose), float(initial_radius), int(lbfgs_max_evals))
         st = _lib.FitStats()
-        rc = self.lib.ppbo_fit_fmap(self.ctx, _ptr(Sigma_inv), N, m, float(sigma), _ptr(f0), C.byref(opts), _ptr(out),
-                                    C.byref(st), self._stream())
-        self._check(rc, "ppbo_fit_fmap")
+        if L is None:
+            rc = self.lib.ppbo_fit_fmap(self.ctx, _ptr(Sigma_inv), N, m, float(sigma), _ptr(f0), C.byref(opts),
+                                        _ptr(out), C.byref(st), self._stream())
+            self._check(rc, "ppbo_fit_fmap")
+        else:
+            rc = self.lib.ppbo_fit_fmap_whitened(self.ctx, _ptr(L), L.stride(0), _ptr(Sigma_inv), N, m, float(sigma),
+                                                 _ptr(f0), C.byref(opts), _ptr(out), C.byref(st), self._stream())
+            self._check(rc, "ppbo_fit_fmap_whitened")
         stats = dict(iterations=st.iterations, n_cholesky=st.n_cholesky, converged=bool(st.converged), T=st.T,
-                     gradnorm=st.gradnorm)
+                     gradnorm=st.gradnorm, lbfgs_iterations=st.lbfgs_iterations, lbfgs_evals=st.lbfgs_evals,
+                     lbfgs_status=st.lbfgs_status)
         return out, stats
 
     def posterior(self, X, theta, kernel, Sigma_inv, fMAP, m, want_P=False) -> Posterior:

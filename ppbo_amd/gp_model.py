@@ -42,6 +42,12 @@ class GPModel:
         self.eng = engine if engine is not None else get_engine()
         self.incremental = bool(incremental)
         self._sinv_state = None      # (X copy, theta tuple, appends since the last full inversion) behind _dSigma_inv
+        self.n_appends = 0           # bordered updates of Sigma^-1 actually performed (ppbo_pd_inverse_append)
+        self.n_full_inversions = 0   # full potrf + trtri + GEMM inversions
+        self.fMAP_restart_on_stall = False   # opt-in: refit from a fresh prior draw when the trust region stalls
+        # "whitened": L-BFGS in z = L^-1 f finished by the trust region (ppbo_fit_fmap_whitened; same optimum as the
+        # reference's trust-exact, O(N^2) per iteration); "trust-region": the exact Newton trust region on f alone
+        self.fMAP_method = "whitened"
         self.fit_log = []            # one dict per update_fMAP trial: iterations, n_cholesky, warm, seconds
         s = PPBO_settings
         self.verbose = s.verbose
@@ -76,7 +82,7 @@ class GPModel:
         self.skip_xstaroptimization_during_initialization = s.skip_xstaroptimization_during_initialization
         self.fit_stats = None
         # device state
-        self._dX = self._dSigma = self._dSigma_inv = self._dLinv = None
+        self._dX = self._dSigma = self._dSigma_inv = self._dLinv = self._dL = None
         self._post = None           # engine.Posterior with G (variance operator)
         self._post_mean = None      # Posterior usable for the mean only (alpha current, no G)
         self._host = {}
@@ -174,19 +180,23 @@ class GPModel:
         th = tuple(float(t) for t in theta)
         st = self._sinv_state
         done = False
-        if (self.incremental and st is not None and st[1] == th and st[2] < APPEND_REFRESH
+        if (self.incremental and st is not None and self._dLinv is not None and st[1] == th and st[2] < APPEND_REFRESH
                 and 0 < self.N - st[0].shape[0] <= 64 and np.array_equal(self.X[:st[0].shape[0]], st[0])):
             try:
                 self._dSigma_inv, self._dLinv = self.eng.pd_inverse_append(self._dSigma, self._dSigma_inv, self._dLinv)
                 self._sinv_state = (self.X.copy(), th, st[2] + 1)
+                self.n_appends += 1
                 done = True
             except NotPositiveDefinite:
                 pass                      # Schur complement lost definiteness to rounding: full inversion below
-        if not done and self.incremental:
-            self._dSigma_inv, self._dLinv = self.eng.pd_inverse_factors(self._dSigma)
-        elif not done:
-            self._dSigma_inv = self.eng.pd_inverse(self._dSigma)
+        self._dL = None
+        if not done:
+            if self.incremental:
+                self._dSigma_inv, self._dLinv = self.eng.pd_inverse_factors(self._dSigma)
+            else:       # the Cholesky factor of Sigma comes with it: the whitened f_MAP search and the prior draws use it
+                (self._dSigma_inv, self._dL), self._dLinv = self.eng.pd_inverse_chol(self._dSigma), None
             self._sinv_state = (self.X.copy(), th, 0)
+            self.n_full_inversions += 1
         self._invalidate("Sigma_inv", "Pinv")
 
     def set_theta(self):
@@ -292,8 +302,11 @@ class GPModel:
         """One Laplace evidence on `eng` from the start vector f0 (device); returns (value incl. log-prior, log-evidence)."""
         import scipy.stats
         Sig = eng.gram(self._dX, theta, self.kernel.__name__, self.COVARIANCE_SHRINKAGE)
-        Sinv = eng.pd_inverse(Sig)
-        fm, st = eng.fit_fmap(Sinv, f0, self.m, theta[0], gtol=1e-4, maxiter=500)
+        if self.fMAP_method == "whitened":
+            Sinv, L = eng.pd_inverse_chol(Sig)
+        else:
+            Sinv, L = eng.pd_inverse(Sig), None
+        fm, st = eng.fit_fmap(Sinv, f0, self.m, theta[0], gtol=1e-4, maxiter=500, L=L)
         _, _, ld, lo = eng.laplace_terms(fm, self.m, theta[0])
         sgn, logdet, _ = eng.laplace_logdet(Sig, ld, lo, self.m)
         log_evidence = st["T"] - 0.5 * sgn * logdet
@@ -326,11 +339,22 @@ class GPModel:
         """evidence() at many thetas: the start vectors are drawn first, in order, from the global stream (so the
         values equal those of sequential evidence() calls), then the independent fits run concurrently on this GPU;
         under torch.distributed (one process per GPU) rank r takes thetas[r::world] and ONE all-gather returns all
-        values to every rank.  NaN / inf -> -500 as in the reference (gp_model.py:314-316)."""
+        values to every rank.  REQUIREMENT under torch.distributed: every rank calls this with the same thetas and
+        an identically seeded global NumPy stream (the start vectors are drawn from it on every rank); a checksum
+        of both is compared across ranks first and a mismatch raises.  NaN / inf -> -500 as in the reference
+        (gp_model.py:314-316)."""
         from . import dist as _dist
         thetas = [[float(t) for t in th] for th in thetas]
         f0s = [self._draw_prior() for _ in thetas]
         rank, world = _dist.rank_world()
+        if world > 1:
+            # rank r evaluates thetas[r::world] and the values are merged BY POSITION: that is only meaningful when
+            # every rank holds the same candidate list and the same start vectors, i.e. identical NumPy streams
+            tarr = np.asarray(thetas, dtype=float)
+            _dist.assert_same_across_ranks(
+                [len(thetas), float(tarr.sum()), float((tarr * np.arange(1, tarr.size + 1).reshape(tarr.shape)).sum()),
+                 float(f0s[0].sum().item()) if f0s else 0.0],
+                "evidence_batch: hyper-parameter candidates / start vectors", device=self.eng.device)
         mine = list(range(rank, len(thetas), world))
         workers = self._default_workers(self.N) if workers is None else workers
         jobs = [(lambda eng, k=k: self._evidence_core(eng, thetas[k], f0s[k])[0]) for k in mine]
@@ -371,6 +395,8 @@ class GPModel:
     def _draw_prior(self):
         """f ~ N(0, Sigma) for the random start (gp_model.py:374,381): L z with the device Cholesky
         factor and z from the global NumPy stream (the reference uses np.random.multivariate_normal)."""
+        if self._dL is not None:          # factor of the current Sigma, from update_Sigma_inv
+            return self.eng.dgemv(self._dL, np.random.standard_normal(self.N), lower=True)
         key = (self._dSigma.data_ptr(), getattr(self._dSigma, "_version", 0))
         cache = self.__dict__.get("_prior_chol")
         if cache is None or cache[0] != key:
@@ -411,7 +437,9 @@ class GPModel:
             starts.append(self.eng.dev(f0))
         # independent restarts (the reference's 10 on the last iteration, gp_model.py:96-97) run concurrently
         t_fit = time.time()
-        jobs = [(lambda eng, f0=f0: eng.fit_fmap(self._dSigma_inv, f0, self.m, self.theta[0], gtol=gtol)) for f0 in starts]
+        L = self._dL if self.fMAP_method == "whitened" else None
+        jobs = [(lambda eng, f0=f0: eng.fit_fmap(self._dSigma_inv, f0, self.m, self.theta[0], gtol=gtol, L=L))
+                for f0 in starts]
         results = self._run_concurrently(jobs, self._default_workers(self.N) if trials > 1 else 1)
         t_fit = (time.time() - t_fit) / max(trials, 1)
         for fm, st in results:
@@ -419,12 +447,16 @@ class GPModel:
                 import torch
                 fm.record_stream(torch.cuda.current_stream(self.eng.device))
             self.fit_log.append(dict(N=self.N, iterations=st["iterations"], n_cholesky=st["n_cholesky"],
+                                     lbfgs_evals=st["lbfgs_evals"], lbfgs_status=st["lbfgs_status"],
                                      converged=st["converged"], warm=bool(warm), seconds=t_fit))
-            if not st["converged"] and not approx_optimization and st["gradnorm"] > 1e3 * gtol:
-                # the trust region stalled far from stationarity (no descent predicted / radius collapsed): the
-                # reference would hand back SciPy's last iterate; one fresh start from the prior is cheap here
+            if (self.fMAP_restart_on_stall and not st["converged"] and not approx_optimization
+                    and st["gradnorm"] > 1e3 * gtol):
+                # opt-in (off by default: it draws from the global NumPy stream, which would shift every later
+                # design relative to the reference's trace).  The trust region stalled far from stationarity (no
+                # descent predicted / radius collapsed): the reference hands back SciPy's last iterate
+                # (gp_model.py:382-389); with the flag set, one fresh start from the prior is tried as well
                 print("---!!!--- f_MAP search stopped at |grad T| = " + str(st["gradnorm"]) + "; restarting from a prior draw")
-                fm2, st2 = self.eng.fit_fmap(self._dSigma_inv, self._draw_prior(), self.m, self.theta[0], gtol=gtol)
+                fm2, st2 = self.eng.fit_fmap(self._dSigma_inv, self._draw_prior(), self.m, self.theta[0], gtol=gtol, L=L)
                 if st2["T"] > st["T"] or not np.isfinite(st["T"]):
                     fm, st = fm2, st2
             if self.verbose:

@@ -1,0 +1,119 @@
+"""a-15: the four outer searches that replace GPyOpt's Bayesian optimisation (src/acquisition.py:91-131, 189-218).
+GPyOpt==1.2.6 is absent, so the search TRAJECTORY cannot be pinned; the objectives (EI, varmax) are
+pinned against the reference elsewhere (test_gpu_golden_r2.py), and the QUALITY of each search is tested here:
+with common random numbers it must reach the 90th percentile of a dense 4096-line sweep of its own domain, and
+more budget (PPBO_settings.BO_maxiter) must never make it worse."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+SWEEP = 4096
+SWEEP_DRAWS = 2000      # the yardstick must not be noise itself: 2000 draws leave ~3 % on a varmax value
+
+
+def _setup(golden, name, acq):
+    from test_gpu_golden_r2 import _fitted
+    x = load_golden(name + "_x")
+    g, gp, st = _fitted(golden, name, acq)
+    gp.xstar, gp.mustar = x["xstar"].copy(), float(x["mustar"])
+    gp.xstars_local = x["xstars_local"].copy()
+    return gp, st
+
+
+def _sweep(gp, st, lines_of, k, which, seed):
+    """Scores of SWEEP uniform lines of the search domain and a scorer for the search's answer, both on ONE set of
+    SWEEP_DRAWS draws (the sweep's own z, independent of the ones the search used)."""
+    from ppbo_amd import acquisition as acq
+    rng = np.random.default_rng(seed)
+    z = rng.standard_normal((SWEEP_DRAWS, acq.LINE_POINTS))
+    U = rng.uniform(0.0, 1.0, (SWEEP, k))
+    vals = []
+    for c in range(0, SWEEP, 512):
+        xis, xs = lines_of(U[c:c + 512])
+        np.random.seed(seed + c)
+        vals.append(acq._line_scores(xis, xs, gp, SWEEP_DRAWS, z=z)[0 if which == "ei" else 1])
+    vals = np.concatenate(vals)
+
+    def score(xi, x):
+        np.random.seed(seed + 99)
+        # the grids carry the reference's 70-point noise (feedback_processing.py:57-74): average a few of them
+        r = [acq._line_scores([xi], [x], gp, SWEEP_DRAWS, z=z)[0 if which == "ei" else 1][0] for _ in range(8)]
+        return float(np.mean(r))
+    return vals, score
+
+
+@pytest.mark.parametrize("name", ["c2", "c3"])
+@pytest.mark.parametrize("fn", ["maximize_EI", "maximize_EI_fixed_x", "maximize_varmax"])
+def test_joint_searches_reach_the_dense_sweeps_top_decile(golden, name, fn):
+    from ppbo_amd import acquisition as acq
+    which = "vm" if fn == "maximize_varmax" else "ei"
+    gp, st = _setup(golden, name, {"maximize_EI": "EI", "maximize_EI_fixed_x": "EI-FIXEDX", "maximize_varmax": "EXR"}[fn])
+    D = gp.D
+    xi_dims = [1, 2]
+    x_dims = [i for i in range(D) if i not in xi_dims]
+    fixed = gp.xstar.copy() if fn == "maximize_EI_fixed_x" else None
+
+    def lines_of(U):
+        xis, xs = np.zeros((len(U), D)), np.zeros((len(U), D))
+        xis[:, xi_dims] = U[:, :2]
+        xs[:, x_dims] = U[:, 2:] if fixed is None else fixed[x_dims]
+        return xis, xs
+
+    k = 2 if fixed is not None else D
+    vals, score = _sweep(gp, st, lines_of, k, which, seed=11)
+    np.random.seed(5)
+    xi, x = getattr(acq, fn)(xi_dims, gp, st)
+    assert np.all(xi[x_dims] == 0) and np.all(x[xi_dims] == 0) and np.all(xi[xi_dims] > 0)
+    if fixed is not None:
+        assert np.allclose(x[x_dims], fixed[x_dims])
+    got = score(xi, x)
+    p90, best = np.percentile(vals, 90), vals.max()
+    log = gp.acq_search_log
+    print(f"{name} {fn}: search {got:.4e}  sweep p50 {np.median(vals):.4e} p90 {p90:.4e} max {best:.4e}  rounds {log}")
+    assert len(log) == 1 + acq.refinement_rounds(st) == 5            # BO_maxiter = 20 -> 4 refinement rounds
+    assert all(b[1] >= a[1] for a, b in zip(log, log[1:]))           # the incumbent never gets worse
+    assert got >= p90 - 1e-12, (got, p90)
+
+
+@pytest.mark.parametrize("name", ["c2", "c3"])
+def test_varmax_given_xi_reaches_the_dense_sweeps_top_decile(golden, name):
+    from ppbo_amd import acquisition as acq
+    gp, st = _setup(golden, name, "COORDINATE-VARMAX")
+    D = gp.D
+    xi = np.zeros(D)
+    xi[0] = 1.0
+    free = list(range(1, D))
+
+    def lines_of(U):
+        xs = np.zeros((len(U), D))
+        xs[:, free] = U
+        return np.tile(xi, (len(U), 1)), xs
+
+    vals, score = _sweep(gp, st, lines_of, D - 1, "vm", seed=21)
+    np.random.seed(6)
+    x = acq.maximize_varmax_given_xi(xi, gp, st)
+    assert x[0] == 0.0 and np.all((x >= 0) & (x <= 1))
+    got = score(xi, x)
+    print(f"{name} maximize_varmax_given_xi: search {got:.4e}  sweep p90 {np.percentile(vals, 90):.4e} max {vals.max():.4e}")
+    assert got >= np.percentile(vals, 90) - 1e-12
+
+
+def test_bo_maxiter_is_the_budget_knob(golden):
+    """PPBO_settings.BO_maxiter (src/ppbo_settings.py:17, consumed at src/acquisition.py:100) sets the number of
+    refinement rounds: 0 -> the uniform round only; with the same seed a larger budget can only improve the
+    (common-random-number) incumbent."""
+    from ppbo_amd import acquisition as acq
+    gp, st = _setup(golden, "c2", "EI")
+    best = []
+    for it in (0, 5, 20, 40):
+        st.BO_maxiter = it
+        np.random.seed(17)
+        acq.maximize_EI([0, 1], gp, st)
+        log = gp.acq_search_log
+        assert len(log) == 1 + int(np.ceil(it / 5))
+        best.append(log[-1][1])
+    assert best[0] <= best[1] <= best[2] <= best[3]
+    assert best[3] > best[0]

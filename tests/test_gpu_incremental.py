@@ -90,7 +90,9 @@ def _replay(golden, incremental):
         gap = float(np.abs(gp.posterior_covariance @ grad.cpu().numpy()).max()) if i >= n_init - 1 else np.inf
         out.append(dict(N=gp.N, fMAP=gp.fMAP.copy(), mustar=gp.mustar, xstar=gp.xstar.copy(), gap=gap,
                         chol=sum(t["n_cholesky"] for t in gp.fit_log[n_log:]),
-                        iters=sum(t["iterations"] for t in gp.fit_log[n_log:]), X=gp.X.copy()))
+                        iters=sum(t["iterations"] for t in gp.fit_log[n_log:]), X=gp.X.copy(),
+                        n_appends=gp.n_appends, n_full=gp.n_full_inversions,
+                        sinv_res=float(np.abs(gp.Sigma @ gp.Sigma_inv - np.eye(gp.N)).max())))
     return g, out
 
 
@@ -102,6 +104,13 @@ def test_incremental_replay_matches_cold_refits(golden):
     g, inc = _replay(golden, True)
     n_init = int(g["n_init"])
     ratio, worst = [], 0.0
+    # the model-level path really borders Sigma^-1 (one append per query after the first full inversion) ...
+    assert cold[-1]["n_appends"] == 0 and cold[-1]["n_full"] == len(cold)
+    assert inc[-1]["n_appends"] >= len(inc) - 2, (inc[-1]["n_appends"], inc[-1]["n_full"])
+    assert inc[-1]["n_appends"] + inc[-1]["n_full"] == len(inc)
+    # ... and the bordered inverse is as good an inverse as the full one
+    for i in range(len(cold)):
+        assert inc[i]["sinv_res"] <= 20 * cold[i]["sinv_res"] + 1e-9, (i, inc[i]["sinv_res"], cold[i]["sinv_res"])
     for i in range(n_init, len(cold)):
         assert np.array_equal(cold[i]["X"], inc[i]["X"])
         scale = np.abs(cold[i]["fMAP"]).max()
@@ -113,3 +122,26 @@ def test_incremental_replay_matches_cold_refits(golden):
     print("factorizations per query cold/incremental:", [(c["chol"], k["chol"]) for c, k in zip(cold[n_init:], inc[n_init:])])
     print(f"worst |f_cold - f_inc| / max|f| = {worst:.2e}")
     assert np.median(ratio) >= 3.0, ratio
+
+
+def test_incremental_switched_on_late_falls_back_to_full_inversion(golden):
+    """incremental toggled on after a non-incremental update: no L^-1 exists yet, so the next update must do a
+    full factor inversion (not call the append with a null factor), and the one after that borders."""
+    from ppbo_amd.gp_model import GPModel
+    from ppbo_amd.ppbo_settings import PPBO_settings
+    g = golden("g7")
+    st = PPBO_settings(D=2, bounds=tuple(map(tuple, g["bounds"])), xi_acquisition_function="PCD", m=int(g["m"]),
+                       theta_initial=list(map(float, g["theta"])), verbose=False)
+    gp = GPModel(st, incremental=False)
+    n_init = int(g["n_init"])
+    for i in range(n_init + 3):
+        if i == n_init - 1:
+            gp.turn_initialization_off()
+        if i == n_init:
+            gp.incremental = True
+        np.random.seed(1000 + i)
+        gp.update_feedback_processing_object(g["X_obs"][:i + 1])
+        gp.update_data()
+        gp.update_model()
+    assert gp.n_full_inversions == n_init + 1 and gp.n_appends == 2
+    assert np.abs(gp.Sigma @ gp.Sigma_inv - np.eye(gp.N)).max() < 1e-6

@@ -1,0 +1,172 @@
+"""a-8 on its production path: f_MAP by L-BFGS in the prior-whitened variable z = L^-1 f, finished by the exact
+trust region (ppbo_fit_fmap_whitened) -- against the reference's trust-exact results in the golden fixtures
+(src/gp_model.py:354-389: same optimum, any path), and against the trust region alone."""
+import numpy as np
+import pytest
+
+from conftest import golden_names
+
+pytestmark = pytest.mark.gpu
+
+FITTED = golden_names(lambda n: n != "c5")
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from ppbo_amd.engine import get_engine
+    return get_engine(0)
+
+
+def _factors(eng, g):
+    S = eng.gram(g["X"], g["theta"], str(g["kernel"]))
+    Sinv, L = eng.pd_inverse_chol(S)
+    return S, Sinv, L
+
+
+@pytest.mark.parametrize("N", [1, 33, 64, 500, 1100])
+def test_pd_inverse_chol_returns_the_factor(eng, N):
+    rng = np.random.default_rng(N)
+    Q = rng.standard_normal((N, N))
+    A = Q @ Q.T + N * np.eye(N)
+    Ai, L = eng.pd_inverse_chol(A)
+    Lh = np.tril(host(L))
+    assert np.abs(Lh - np.linalg.cholesky(A)).max() <= 1e-12 * np.abs(Lh).max()
+    assert np.array_equal(host(Ai), host(eng.pd_inverse(A)))          # same kernels, same bits
+    assert np.abs(host(Ai) @ A - np.eye(N)).max() < 1e-10
+
+
+@pytest.mark.parametrize("name", FITTED)
+def test_whitened_fit_vs_reference(eng, golden, name):
+    """The assertions of test_gpu_parity.py::test_fit_fmap_vs_reference, on the whitened path: reference-evaluated
+    gradient norm not above the reference's own, distance within 1e-5 max|f| + the reference's Newton gap, T at
+    least the reference's -- at a tolerance (1e-6) below the reference's stopping rule, so the hand-over to the
+    trust-region finisher is exercised too."""
+    g = golden(name)
+    m, sig = int(g["m"]), float(g["theta"][0])
+    _, Sinv, L = _factors(eng, g)
+    fmap, st = eng.fit_fmap(Sinv, g["f_init"], m, sig, gtol=1e-6, L=L)
+    print(name, st)
+    f = host(fmap)
+    assert st["converged"] and st["lbfgs_evals"] > 0
+    assert st["n_cholesky"] <= 3, "the finisher should need at most a Newton step or two"
+    _, grad = eng.T_and_grad(Sinv, f, m, sig)
+    gn = np.linalg.norm(host(grad))
+    assert gn <= max(float(g["gradnorm_fMAP"]), 2e-6)
+    post = eng.posterior(g["X"], g["theta"], str(g["kernel"]), Sinv, g["fMAP"], m, want_P=True)
+    _, gref = eng.T_and_grad(Sinv, g["fMAP"], m, sig)
+    ref_gap = np.abs(host(post.P) @ host(gref)).max()
+    assert np.abs(f - g["fMAP"]).max() <= 1e-5 * np.abs(g["fMAP"]).max() + 1.5 * ref_gap
+    assert st["T"] >= float(g["T_fMAP"]) - 1e-7 * max(1.0, abs(float(g["T_fMAP"])))
+
+
+@pytest.mark.parametrize("name", FITTED)
+def test_whitened_fit_stops_on_the_reference_rule_without_factorizations(eng, golden, name):
+    """At the reference's own tolerance (SciPy's gtol = 1e-4 on |grad_f T|) the whitened search ends by that very
+    rule, no Cholesky of the Hessian is ever formed, and it agrees with the exact trust-region Newton on f."""
+    g = golden(name)
+    m, sig = int(g["m"]), float(g["theta"][0])
+    _, Sinv, L = _factors(eng, g)
+    fw, sw = eng.fit_fmap(Sinv, g["f_init"], m, sig, gtol=1e-4, L=L)
+    ft, stt = eng.fit_fmap(Sinv, g["f_init"], m, sig, gtol=1e-4)
+    print(name, "whitened", sw, "| trust region", stt)
+    assert sw["converged"] and sw["gradnorm"] < 1e-4
+    if sw["lbfgs_status"] == 1:
+        assert sw["n_cholesky"] == 0 and sw["iterations"] == 0
+    else:                                   # stalled at the rounding floor just above 1e-4: one Newton step finishes it
+        assert sw["n_cholesky"] <= 2
+    assert stt["lbfgs_status"] == -1 and stt["n_cholesky"] >= 3
+    post = eng.posterior(g["X"], g["theta"], str(g["kernel"]), Sinv, fw, m, want_P=True)
+    P = host(post.P)
+    gaps = []
+    for f in (fw, ft):                      # both stop at |grad| < 1e-4: compare up to their own Newton gaps
+        _, gr = eng.T_and_grad(Sinv, f, m, sig)
+        gaps.append(np.abs(P @ host(gr)).max())
+    assert np.abs(host(fw) - host(ft)).max() <= 1e-5 * np.abs(g["fMAP"]).max() + 1.5 * sum(gaps)
+    assert abs(sw["T"] - stt["T"]) <= 1e-6 * max(1.0, abs(stt["T"]))
+
+
+def test_whitened_fit_is_deterministic_and_reentrant(eng, golden):
+    g = golden("c2")
+    m, sig = int(g["m"]), float(g["theta"][0])
+    _, Sinv, L = _factors(eng, g)
+    a, sa = eng.fit_fmap(Sinv, g["f_init"], m, sig, L=L)
+    b, sb = eng.fit_fmap(Sinv, g["f_init"], m, sig, L=L)
+    assert np.array_equal(host(a), host(b)) and sa == sb
+    # a start AT the optimum (|grad| < gtol there already): a handful of evaluations, no factorization, and the
+    # point does not move by more than the Newton gap of a fit stopped at |grad| < 1e-4
+    c, sc = eng.fit_fmap(Sinv, a, m, sig, L=L)
+    assert sc["lbfgs_evals"] <= 4 and sc["n_cholesky"] == 0
+    assert np.abs(host(c) - host(a)).max() <= 1e-6 * np.abs(host(a)).max()
+
+
+def test_whitened_fit_budget_hands_over_to_the_trust_region(eng, golden):
+    """An evaluation budget that ends the pre-phase early: the finisher completes the fit from where it stopped."""
+    g = golden("c2")
+    m, sig = int(g["m"]), float(g["theta"][0])
+    _, Sinv, L = _factors(eng, g)
+    f, st = eng.fit_fmap(Sinv, g["f_init"], m, sig, L=L, lbfgs_max_evals=10)
+    assert st["lbfgs_status"] == 5 and 10 <= st["lbfgs_evals"] <= 12
+    assert st["converged"] and st["n_cholesky"] > 0
+    full, _ = eng.fit_fmap(Sinv, g["f_init"], m, sig, L=L)
+    assert np.abs(host(f) - host(full)).max() <= 1e-4 * np.abs(host(full)).max()
+
+
+def test_whitened_fit_rejects_bad_arguments(eng, golden):
+    g = golden("smoke")
+    m, sig = int(g["m"]), float(g["theta"][0])
+    _, Sinv, L = _factors(eng, g)
+    bad = g["f_init"].copy()
+    bad[3] = np.nan
+    with pytest.raises(RuntimeError):
+        eng.fit_fmap(Sinv, bad, m, sig, L=L)
+    with pytest.raises(RuntimeError):
+        eng.fit_fmap(Sinv, g["f_init"][:-1], m, sig, L=L)
+
+
+def test_c5_cold_fit_whitened(eng, golden):
+    """BASELINE config 5's cold fit (N = 4096, sigma = 0.001, camphor kernel) from a prior draw: 512 trust-region
+    iterations / 1239 factorizations / 2.6 s on the exact path (tests/test_gpu_c5.py); the whitened search lands on
+    the same reference-certified optimum with at most a couple of factorizations."""
+    import time
+    import torch
+    g = golden("c5")
+    m, sig = int(g["m"]), float(g["theta"][0])
+    N = g["X"].shape[0]
+    _, Sinv, L = _factors(eng, g)
+    f0 = eng.dgemv(L, np.random.default_rng(2).standard_normal(N), lower=True)
+    eng.fit_fmap(Sinv, f0, m, sig, gtol=1e-7, L=L)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fm, st = eng.fit_fmap(Sinv, f0, m, sig, gtol=1e-7, L=L)
+    torch.cuda.synchronize()
+    print(f"C5 cold fit, whitened: {(time.perf_counter() - t0) * 1e3:.1f} ms", st)
+    assert st["converged"] and st["lbfgs_evals"] > 20 and st["n_cholesky"] <= 4
+    f = host(fm)
+    _, grad = eng.T_and_grad(Sinv, f, m, sig)
+    assert np.linalg.norm(host(grad)) <= max(float(g["gradnorm_fMAP"]), 2e-6)
+    post = eng.posterior(g["X"], g["theta"], str(g["kernel"]), Sinv, g["fMAP"], m, want_P=True)
+    _, gref = eng.T_and_grad(Sinv, g["fMAP"], m, sig)
+    ref_gap = np.abs(host(post.P) @ host(gref)).max()
+    assert np.abs(f - g["fMAP"]).max() <= 1e-5 * np.abs(g["fMAP"]).max() + 1.5 * ref_gap
+    assert st["T"] >= float(g["T_fMAP"]) - 1e-7 * max(1.0, abs(float(g["T_fMAP"])))
+
+
+def test_drop_in_uses_the_whitened_search_by_default(golden):
+    from test_gpu_dropin import _model
+    g = golden("c2")
+    gp, st = _model(g, "PCD")
+    gp.turn_initialization_off()
+    np.random.seed(3)
+    gp.update_model()
+    log = gp.fit_log[-1]
+    assert gp.fMAP_method == "whitened" and log["lbfgs_evals"] > 0 and log["n_cholesky"] <= 2
+    f_w = gp.fMAP.copy()
+    gp.fMAP_method = "trust-region"
+    np.random.seed(3)
+    gp.update_model()
+    assert gp.fit_log[-1]["lbfgs_evals"] == 0 and gp.fit_log[-1]["n_cholesky"] > 10
+    assert np.abs(f_w - gp.fMAP).max() <= 2e-4 * np.abs(gp.fMAP).max()      # two fits stopped at |grad| < 1e-4

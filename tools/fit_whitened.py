@@ -1,0 +1,29 @@
+"""f_MAP by the whitened L-BFGS (+ trust-region finisher) vs the trust region alone, per golden fixture:
+evaluations / factorizations, wall time, distance to the reference's f_MAP.
+    python tools/fit_whitened.py [names] [gtol] [verbose]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from ppbo_amd.engine import get_engine
+eng = get_engine(0)
+names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["smoke", "rq", "cam_small", "c2", "c4", "c3", "c5"]
+gtol = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-4
+verbose = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+for name in names:
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"{name}.npz")))
+    m, th = int(g["m"]), g["theta"]
+    S = eng.gram(g["X"], th, str(g["kernel"]))
+    Sinv, L = eng.pd_inverse_chol(S)
+    f0 = eng.dev(g["f_init"])
+    for mode in ("whitened", "tr"):
+        if mode == "tr" and name == "c5":
+            continue
+        kw = dict(L=L) if mode == "whitened" else {}
+        eng.fit_fmap(Sinv, f0, m, th[0], gtol=gtol, **kw)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        f, st = eng.fit_fmap(Sinv, f0, m, th[0], gtol=gtol, verbose=verbose, **kw)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
+        _, gr = eng.T_and_grad(Sinv, f, m, th[0])
+        print(f"{name:10s} {mode:8s} {dt:8.2f} ms  lbfgs it/ev/status {st['lbfgs_iterations']}/{st['lbfgs_evals']}/{st['lbfgs_status']}"
+              f"  TR it {st['iterations']} chol {st['n_cholesky']}  |grad_f| {float(torch.linalg.norm(gr)):.2e} (ref {float(g['gradnorm_fMAP']):.2e})"
+              f"  T {st['T']:.12f} (ref {float(g['T_fMAP']):.12f})  max|f-fref| {np.abs(f.cpu().numpy() - g['fMAP']).max():.2e}", flush=True)
