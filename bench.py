@@ -94,6 +94,87 @@ def cpu_baseline(g, M_sample, seconds_budget=25.0, gpu_check=None):
                 parity_vs_oracle=parity)
 
 
+
+def per_query_breakdown(torch, reps=5):
+    """One PPBO iteration on the C2 shape (Hartmann6-like: D = 6, N = 512, theta = [0.001, 0.26, 0.1]) through the
+    drop-in objects, phase by phase (ms, median of `reps`): what GPModel.update_model + next_query cost per query
+    (ppbo_numerical_main.py:86-92,107-124).  fit_cold = update_Sigma + update_Sigma_inv + update_fMAP (a fresh prior
+    draw, the reference's default) + posterior; fit_incremental = the same after ONE appended query with
+    GPModel(incremental=True) (bordered Sigma^-1, warm start); mu_star = ONE trial of the device-resident search
+    (the reference's default is 3 per iteration); next_query = EI-EXT-FAST (D lines, 150 draws) and the EI joint
+    search (BO_maxiter = 20)."""
+    from ppbo_amd.acquisition import next_query
+    from ppbo_amd.gp_model import GPModel
+    from ppbo_amd.ppbo_settings import PPBO_settings
+    g = synth_model_inputs("c2")
+    D, m = int(g["D"]), int(g["m"])
+
+    def model(acq, n_q, incremental=False):
+        st = PPBO_settings(D=D, bounds=tuple(map(tuple, g["bounds"])), xi_acquisition_function=acq,
+                           theta_initial=list(map(float, g["theta"])), m=m, verbose=False, kernel=str(g["kernel"]))
+        gp = GPModel(st, incremental=incremental)
+        np.random.seed(0)
+        gp.update_feedback_processing_object(g["X_obs"][:n_q])
+        gp.update_data()
+        gp.turn_initialization_off()
+        return gp, st
+
+    def med(fn, n=reps):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts))
+
+    n_q = g["X_obs"].shape[0]
+    gp, st = model("EI-EXT-FAST", n_q)
+
+    def fit_cold():
+        gp.update_Sigma(gp.theta)
+        gp.update_Sigma_inv(gp.theta)
+        gp.update_fMAP()
+        gp._post = gp.eng.posterior(gp._dX, gp.theta, gp.kernel.__name__, gp._dSigma_inv, gp.eng.dev(gp.fMAP), gp.m)
+        gp._post_mean = gp._post
+
+    gp.set_theta()
+    np.random.seed(1)
+    fit_cold()
+    out = {"shape": f"C2: N={gp.N}, D={D}, m={m}, theta={list(map(float, g['theta']))}"}
+    out["fit_cold_ms"] = med(fit_cold)
+    out["fit_cold_lbfgs_evals"] = gp.fit_log[-1]["lbfgs_evals"]
+    gp.mu_star(mustar_finding_trials=1)
+    out["mu_star_ms_per_trial"] = med(lambda: gp.mu_star(mustar_finding_trials=4)) / 4.0
+    gp.xstar, gp.mustar, gp.xstars_local = gp.mu_star()
+    next_query(st, gp)
+    out["next_query_EI_EXT_FAST_ms"] = med(lambda: next_query(st, gp))
+    st.xi_acquisition_function = "EI"
+    st.xi_dims_prev_iter = [0, 1]
+    next_query(st, gp)
+    out["next_query_EI_search_ms"] = med(lambda: next_query(st, gp), 3)
+    # incremental: fit n_q - 1 queries, then time the update that appends the last one
+    ts = []
+    for _ in range(3):
+        gi, _ = model("PCD", n_q - 1, incremental=True)
+        np.random.seed(2)
+        gi.update_model()
+        gi.update_feedback_processing_object(g["X_obs"][:n_q])
+        gi.update_data()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gi.update_Sigma(gi.theta)
+        gi.update_Sigma_inv(gi.theta)
+        gi.update_fMAP()
+        gi._post = gi.eng.posterior(gi._dX, gi.theta, gi.kernel.__name__, gi._dSigma_inv, gi.eng.dev(gi.fMAP), gi.m)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+        assert gi.n_appends == 1
+    out["fit_incremental_ms"] = float(np.median(ts))
+    out["fit_incremental_cholesky"] = gi.fit_log[-1]["n_cholesky"]
+    return out
+
 # BASELINE.json configs that have a committed design fixture: name, default candidate count, default scaling
 WORKLOADS = {
     "c2": ("C2 Hartmann6-shaped", 16384, "weak"),
@@ -207,7 +288,7 @@ def main():
             Sinv, Lc = eng.pd_inverse_chol(Sigma)
         else:
             Sinv, Lc = eng.pd_inverse(Sigma), None
-        fmap, st = eng.fit_fmap(Sinv, f_init, m, th[0], gtol=1e-4, L=Lc)
+        fmap, st = eng.fit_fmap(Sinv, f_init, m, th[0], gtol=1e-4, L=Lc, Sigma=Sigma if whitened else None)
         post = eng.posterior(Xd, th, kern, Sinv, fmap, m)
         return post, st
     post, st = fit_once()            # warm (allocates workspaces)
@@ -379,6 +460,10 @@ def main():
             "rff_score_evals_per_s": M / t_rs, "rff_score_kernel_ms": rs_ms / max(rs_n, 1),
             "line_acq": {"lines": B, "grid": G, "draws": S, "ms": t_line * 1e3, "lines_per_s": B / t_line},
         }
+        try:
+            secondary["per_query_ms"] = per_query_breakdown(torch)
+        except Exception as exc:      # noqa: BLE001  -- a secondary row must never cost the headline line
+            secondary["per_query_ms"] = {"error": repr(exc)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

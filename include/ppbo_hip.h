@@ -71,6 +71,11 @@ int ppbo_profile_read(ppbo_ctx* ctx, const char* name, double* h_total_ms, int* 
 int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D,
               const double h_theta[3], double shrink, double* d_Sigma, void* stream);
 
+/* measurement probe, not part of the path: a write-only pass over d_S[N,N] (32 x 128 tiles, 16-byte write-through
+ * stores, the fastest store shape tools/store_floor.hip found): the ceiling of ANY Gram kernel at that N on this
+ * chip.  bench.py times it beside ppbo_gram (`write_only_floor_*`) instead of quoting constants. */
+int ppbo_store_floor(ppbo_ctx* ctx, double* d_S, int N, void* stream);
+
 /* ---- K2: raw cross-covariance ------------------------------------------
  * replaces GPModel.create_Gramian_nonsquare (src/gp_model.py:153-155).
  * d_X1[n1,D], d_X2[n2,D] -> d_K[n1,n2] (row stride ldk >= n2). */
@@ -110,6 +115,12 @@ int ppbo_pd_inverse_ex(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, 
  * results.  PPBO_ERR_NOT_PD (info = failing column of A) when S is not positive definite. */
 int ppbo_pd_inverse_append(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, const double* d_L11inv,
                            int N1, double* d_Ainv, double* d_Linv, int* h_info, void* stream);
+/* ... that also borders the factor itself: d_L11[N1,N1] (row stride N1, lower triangle = factor of the leading block,
+ * as ppbo_pd_inverse_ex or a previous call returned it) -> d_L[N,N] = [[L11, 0], [Y^T, L22]], so the appended design
+ * can go straight into ppbo_fit_fmap_whitened.  d_L11 and d_L are both NULL or both given. */
+int ppbo_pd_inverse_append_ex(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, const double* d_L11inv,
+                              const double* d_L11, int N1, double* d_Ainv, double* d_Linv, double* d_L, int* h_info,
+                              void* stream);
 
 /* ---- K5: Laplace terms of the projective-preference likelihood -----------
  * replaces sum_Phi/sum_Phi_vec (src/gp_model.py:176-218), the likelihood part of
@@ -160,11 +171,15 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
  * tens of O(N^3) factorizations.  It stops on the reference's own rule |grad_f T|_2 < gtol; whatever is left
  * (a request below the rounding floor of the whitened iteration, a stalled line search) is finished by
  * ppbo_fit_fmap from the point reached, so the result satisfies exactly what ppbo_fit_fmap's does.
+ * d_Sigma (optional, may be NULL): Sigma itself.  With it an evaluation is TWO launches instead of five to six:
+ * f = L z and v = Sigma^-1 f are linear in z and are carried along as images of the iteration's vectors, and the
+ * only matrix products left, L^T beta and Sigma beta, share one kernel (a dependent launch costs ~8 us on
+ * MI355X however small it is).
  * Same optimum as the reference on every golden fixture; the PATH (and hence, on a multi-modal posterior, which
  * local maximum is found) is not SciPy's. */
-int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m,
-                           double sigma, const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
-                           ppbo_fit_stats* h_stats, void* stream);
+int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma,
+                           const double* d_Sigma_inv, int N, int m, double sigma, const double* d_f_init,
+                           const ppbo_fit_opts* opts, double* d_fMAP, ppbo_fit_stats* h_stats, void* stream);
 
 /* T(f) and grad T(f) for a given f (src/gp_model.py:221-240); h_T / d_grad may be NULL */
 int ppbo_T_and_grad(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_f, int N, int m,
@@ -219,6 +234,22 @@ int ppbo_predict_cov(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc,
  * model are read. */
 int ppbo_mean_grad(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
                    double* d_mu, double* d_grad, void* stream);
+
+/* ---- f-2, device-resident: the maximiser of the posterior mean ---------------------------------------
+ * replaces GPModel.mu_star's differential evolution (src/gp_model.py:415-437: ~2 k ... 17 k sequential mu_pred
+ * calls per trial) by one enqueue: score the M candidates (ppbo_predict, mean only), thin them to <= 4096 group
+ * winners, pick the K best that are pairwise more than `sep` apart, and run a projected Barzilai-Borwein gradient
+ * ascent from each -- the WHOLE iteration inside one kernel, one workgroup per start, no host round trip.
+ * d_x[K,D] / d_mu[K]: the refined maxima (rows >= *h_found: mu = -inf).  h_found may be NULL (then nothing
+ * synchronises).  ppbo_mean_ascent is the last stage alone, from caller-chosen starts (d_iters[K] optional).
+ * ppbo_shift_points: d_out = frac(d_in + h_shift[D]) row-wise -- a rotation of a RESIDENT uniform candidate pool,
+ * so that repeated searches see fresh candidates without regenerating and uploading M x D numbers. */
+int ppbo_mean_search(ppbo_ctx* ctx, const ppbo_model* model, const double* d_cand, int64_t M, int K, double sep,
+                     int iters, double tol, double* d_x, double* d_mu, int* h_found, void* stream);
+int ppbo_mean_ascent(ppbo_ctx* ctx, const ppbo_model* model, const double* d_starts, int K, int iters, double tol,
+                     double* d_x, double* d_mu, int* d_iters, void* stream);
+int ppbo_shift_points(ppbo_ctx* ctx, const double* d_in, int64_t M, int D, const double* h_shift, double* d_out,
+                      void* stream);
 
 /* ---- K10: Monte-Carlo line acquisition -------------------------------------
  * replaces EI / varmax (src/acquisition.py:72-81, 170-178) for B lines of G points

@@ -50,20 +50,25 @@ SIGNATURES = {
     "ppbo_profile_reset": [_vp],
     "ppbo_profile_read": [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(_i)],
     "ppbo_gram": [_vp, _i, _vp, _i, _i, _dp3, _d, _vp, _vp],
+    "ppbo_store_floor": [_vp, _vp, _i, _vp],
     "ppbo_cross_cov": [_vp, _i, _vp, _i, _vp, _i, _i, _dp3, _vp, _i, _vp],
     "ppbo_potrf": [_vp, _vp, _i, _i, C.POINTER(_i), _vp],
     "ppbo_pd_inverse": [_vp, _vp, _i, _vp, C.POINTER(_i), _vp],
     "ppbo_pd_inverse_factors": [_vp, _vp, _i, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_pd_inverse_ex": [_vp, _vp, _i, _vp, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_pd_inverse_append": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, C.POINTER(_i), _vp],
+    "ppbo_pd_inverse_append_ex": [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_laplace_terms": [_vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp],
     "ppbo_fit_fmap": [_vp, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
-    "ppbo_fit_fmap_whitened": [_vp, _vp, _i, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
+    "ppbo_fit_fmap_whitened": [_vp, _vp, _i, _vp, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
     "ppbo_T_and_grad": [_vp, _vp, _vp, _i, _i, _d, C.POINTER(_d), _vp, _vp],
     "ppbo_posterior": [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_predict": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _vp, _vp, _vp, C.POINTER(_d), C.POINTER(_i64), _vp],
     "ppbo_predict_cov": [_vp, C.POINTER(Model), _vp, _i, _d, _vp, _vp, _vp],
     "ppbo_mean_grad": [_vp, C.POINTER(Model), _vp, C.c_int64, _vp, _vp, _vp],
+    "ppbo_mean_search": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _i, _d, _vp, _vp, C.POINTER(_i), _vp],
+    "ppbo_mean_ascent": [_vp, C.POINTER(Model), _vp, _i, _i, _d, _vp, _vp, _vp, _vp],
+    "ppbo_shift_points": [_vp, _vp, _i64, _i, C.POINTER(_d), _vp, _vp],
     "ppbo_line_acq": [_vp, C.POINTER(Model), _vp, _i, _i, _d, _vp, _i, _d, _d, _vp, _vp, _vp],
     "ppbo_rff_project": [_vp, _vp, _i, _i, _vp, _i, _vp, _d, _vp, _vp],
     "ppbo_rff_score": [_vp, _vp, _i64, _i, _vp, _i, _vp, _d, _vp, _vp, C.POINTER(_d), C.POINTER(_i64), _vp],

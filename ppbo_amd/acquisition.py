@@ -29,18 +29,31 @@ ITERS_PER_ROUND = 5
 SEARCH_DRAW_FACTOR = 8
 
 
-def _line_scores(xis, xs, GP_model, mc_samples, z=None):
+def _line_scores(xis, xs, GP_model, mc_samples, z=None, alphas=None):
     """EI and varmax of B lines in one device call.  Grid noise (and z unless given) come from the global NumPy
-    stream; a caller comparing lines passes ONE z so that every line sees the same draws (common random numbers)."""
+    stream; a caller comparing lines passes ONE z -- and ONE set of grid abscissae `alphas` (the 70 noisy-equispaced
+    alpha of FP.xi_grid, drawn once) -- so that every line sees the same draws (common random numbers)."""
     FP = GP_model.FP
-    grids = np.stack([FP.xi_grid(xi=xi, x=x, alpha_grid_distribution="equispaced", alpha_star=None, m=LINE_POINTS,
-                                 is_scaled=True) for xi, x in zip(xis, xs)])
+    if alphas is None:
+        grids = np.stack([FP.xi_grid(xi=xi, x=x, alpha_grid_distribution="equispaced", alpha_star=None, m=LINE_POINTS,
+                                     is_scaled=True) for xi, x in zip(xis, xs)])
+    else:       # what xi_grid(is_scaled=True) returns for each line, for one shared alpha vector
+        grids = alphas[None, :, None] * np.asarray(xis, dtype=float)[:, None, :] + np.asarray(xs, dtype=float)[:, None, :]
     if z is None:
         z = np.random.standard_normal((mc_samples, LINE_POINTS))
     sf2 = float(GP_model.theta[2]) ** 2
     ei, vm = GP_model.eng.line_acq(GP_model._post, grids, z, GP_model.mustar, GP_model.COVARIANCE_SHRINKAGE,
                                    jitter=1e-10 * sf2)
     return ei.cpu().numpy(), vm.cpu().numpy()
+
+
+def _noisy_alphas():
+    """One draw of the reference's 70 noisy-equispaced abscissae on [0, 1] (feedback_processing.py:57-74, is_scaled)."""
+    while True:
+        a = np.linspace(0.005, 0.995, LINE_POINTS) + np.random.normal(0.0, 0.01, LINE_POINTS)
+        a = np.unique(np.clip(a, 0.0, 1.0))
+        if a.size == LINE_POINTS:
+            return a
 
 
 def EI(xi, x, GP_model, mc_samples):
@@ -70,15 +83,17 @@ def _batched_search(k, lines_of, GP_model, PPBO_settings, which):
     launch -- SEARCH_LINES uniform draws, then refinement_rounds() rounds of REFINE_LINES Gaussian perturbations of
     the REFINE_PARENTS best lines so far with a width that halves every round (0.2, 0.1, ... of the unit box) --
     all with ONE set of SEARCH_DRAW_FACTOR x mc_samples Monte-Carlo draws, so lines are ranked by common random
-    numbers instead of by 150-draw noise; the best REFINE_PARENTS then meet in a play-off on fresh draws.
+    numbers (one z, one noisy alpha grid) instead of by 150-draw noise; the best REFINE_PARENTS then meet in a
+    play-off on four times as many fresh draws.
     Returns the best u and a log [(round, best value so far)]."""
     draws = SEARCH_DRAW_FACTOR * int(PPBO_settings.mc_samples)
     z = np.random.standard_normal((draws, LINE_POINTS))
+    alphas = _noisy_alphas()
     pick = 0 if which == "ei" else 1
 
-    def score(U, zz=z):
+    def score(U, zz=z, aa=alphas):
         xis, xs = lines_of(U)
-        return _line_scores(xis, xs, GP_model, draws, z=zz)[pick]
+        return _line_scores(xis, xs, GP_model, len(zz), z=zz, alphas=aa)[pick]
 
     U = np.random.uniform(0.0, 1.0, (SEARCH_LINES, k))
     V = score(U)
@@ -93,7 +108,7 @@ def _batched_search(k, lines_of, GP_model, PPBO_settings, which):
     # play-off: the incumbents' values are biased upwards by their own selection; the REFINE_PARENTS best are
     # re-scored on an independent set of draws (and fresh grid noise) and the winner is chosen on those alone
     finalists = U[np.argsort(-V)[:REFINE_PARENTS]]
-    V2 = score(finalists, np.random.standard_normal((draws, LINE_POINTS)))
+    V2 = score(finalists, np.random.standard_normal((4 * draws, LINE_POINTS)), _noisy_alphas())
     return finalists[int(np.argmax(V2))], log
 
 

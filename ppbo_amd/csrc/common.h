@@ -22,7 +22,7 @@ struct ppbo_ctx {
   int device = 0;
   std::string err;
   // named workspace slots
-  enum { WS_KSTAR = 0, WS_PART, WS_SCRATCH, WS_LINALG, WS_LINALG2, WS_VEC, WS_SMALL, WS_POTRF, WS_APPEND, WS_DIST, WS_LBFGS, WS_COUNT };
+  enum { WS_KSTAR = 0, WS_PART, WS_SCRATCH, WS_LINALG, WS_LINALG2, WS_VEC, WS_SMALL, WS_POTRF, WS_APPEND, WS_DIST, WS_LBFGS, WS_SEARCH, WS_SEARCH_SMALL, WS_LBFGS_IMG, WS_COUNT };
   void* ws[WS_COUNT] = {};
   size_t ws_bytes[WS_COUNT] = {};
   void* pinned = nullptr;  // small pinned host staging buffer
@@ -35,7 +35,7 @@ struct ppbo_ctx {
   // kernels whose dynamic-LDS limit has been raised on THIS ctx's device (hipFuncSetAttribute is per device)
   std::vector<const void*> lds_raised;
   // tuning knobs, read from the environment once per ctx (ppbo_ctx_create); defaults = measured best
-  int qf_variant = 2, qf_order = 258, potrf_gen = 3, rff_nt = 0, gram_variant = 0;
+  int qf_variant = 2, qf_order = 258, potrf_gen = 3, rff_nt = 0, gram_variant = -1;
   ppbo_dist_state* dist = nullptr;   // set by ppbo_dist_init
 };
 

@@ -218,8 +218,22 @@ __global__ __launch_bounds__(256) void g_build_kernel(const double* __restrict__
                                                       const double* __restrict__ lam_diag,
                                                       const double* __restrict__ lam_off, double* __restrict__ G) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= N) return;
   const double* r = R + (size_t)blockIdx.y * N;
+  if (mblk == 32 && (N & 31) == 0) {
+    // a star is exactly one aligned half-wavefront: the observation column's sum over its star comes from the
+    // other 31 lanes by shuffles instead of a 31-iteration loop in one lane (which held the whole wavefront:
+    // 125 us for 2 x 33 MB at N = 2048)
+    const bool in = j < N;            // N % 32 == 0: a half-wavefront is entirely inside or entirely outside
+    const double rj = in ? r[j] : 0.0, ld = in ? lam_diag[j] : 0.0, lo = in ? lam_off[j] : 0.0;
+    const bool obs = (j & 31) == 0;
+    double t = obs ? rj * ld : rj * lo;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    const double r0 = __shfl(rj, (threadIdx.x & 63) & ~31, 64);
+    if (in) G[(size_t)blockIdx.y * N + j] = obs ? t : rj * ld + r0 * lo;
+    return;
+  }
+  if (j >= N) return;
   const int q0 = (j / mblk) * mblk;
   double acc = r[j] * lam_diag[j];
   if (j != q0) {
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(1024) void restep_kernel(const double* __restrict__
 // possible (|grad_f| >= |grad_z| / |L|_F).
 constexpr int LB_H = 8;                 // history pairs
 constexpr int LB_NB = 2 * LB_H + 1;     // basis vectors: s ring [0,H), y ring [H,2H), current gradient 2H
-constexpr int LB_T = 1024;              // threads of the step workgroup
+constexpr int LB_T = 1024;              // threads of the step workgroup: two elements each at N = 2048
 constexpr int LB_MAX_BACKTRACK = 12;
 
 struct WhState {
@@ -287,6 +301,7 @@ struct WhState {
   int evals, iters, hist, head, first, ls, stall, need_gf, max_evals;
   double phi, dphi, alpha, gz2, gf2, gate, gtol2;
   double B[LB_NB * LB_NB];
+  double delta[LB_NB];   // coefficients (over the basis) of the direction behind the current trial point
 };
 
 // rowsq[i] = sum_{k <= i} L[i][k]^2 (= Sigma_ii); their sum is |L|_F^2 >= lambda_max(Sigma)
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const double* __restric
 
 __global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ st, const double* __restrict__ rowsq,
                                                           int N, double gtol, int max_evals) {
-  __shared__ double sh[16];
+  __shared__ double sh[LB_T / 64];
   double s = 0.0;
   for (int i = threadIdx.x; i < N; i += LB_T) s += rowsq[i];
   s = wave_sum(s);
@@ -312,7 +327,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ 
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
-    for (int w = 0; w < 16; ++w) t += sh[w];
+    for (int w = 0; w < LB_T / 64; ++w) t += sh[w];
     st->status = 0; st->evals = 0; st->iters = 0; st->hist = 0; st->head = 0; st->first = 1; st->ls = 0;
     st->stall = 0; st->need_gf = 0; st->max_evals = max_evals;
     st->phi = 0.0; st->dphi = 0.0; st->alpha = 0.0; st->gz2 = 0.0; st->gf2 = -1.0;
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ 
   }
 }
 
-template <int K>
+template <int K, int NT>
 __device__ __forceinline__ void lb_block_sum(double (&v)[K], double* __restrict__ red, double* __restrict__ out) {
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
@@ -333,7 +348,7 @@ __device__ __forceinline__ void lb_block_sum(double (&v)[K], double* __restrict_
   __syncthreads();
   if (threadIdx.x < K) {
     double t = 0.0;
-    for (int ww = 0; ww < LB_T / 64; ++ww) t += red[ww * K + threadIdx.x];
+    for (int ww = 0; ww < NT / 64; ++ww) t += red[ww * K + threadIdx.x];
     out[threadIdx.x] = t;
   }
   __syncthreads();
@@ -342,42 +357,83 @@ __device__ __forceinline__ void lb_block_sum(double (&v)[K], double* __restrict_
 // One judgement of the trial point zt (its products u = L^T beta(L zt), v = Sigma^-1 L zt and the per-query
 // likelihood sums tq are already in memory).  See the block comment above; tests/probes/whitened_lbfgs_proto.py is
 // the NumPy statement of the same recurrence.
-__global__ __launch_bounds__(LB_T) void lbfgs_step_kernel(WhState* __restrict__ st, int N, int m, int n_q,
-                                                          double* __restrict__ z, double* __restrict__ zt,
-                                                          double* __restrict__ d, const double* __restrict__ u,
-                                                          const double* __restrict__ v,
-                                                          const double* __restrict__ beta,
-                                                          const double* __restrict__ tq, double* __restrict__ basis) {
+// The scalar head of WhState (everything before B), as the step works on it in LDS: global memory is read once at
+// the start and written once at the end -- a thread that loads, computes, stores and loads again from global memory
+// pays ~1 us per dependent access, which made the first version of this function take 25-45 us.
+struct WhHead {
+  int status, evals, iters, hist, head, first, ls, stall, need_gf, max_evals;
+  double phi, dphi, alpha, gz2, gf2, gate, gtol2;
+};
+static_assert(sizeof(WhHead) == offsetof(WhState, B), "WhHead mirrors the head of WhState");
+
+// One judgement of the trial point zt (its products u = L^T beta(L zt), v = Sigma^-1 L zt and the per-query
+// likelihood sums tq are already in memory).  tests/probes/whitened_lbfgs_proto.py is the NumPy statement of the
+// recurrence.  TWO passes over the N-vectors and one block reduction:
+//   pass 1   objective, |grad_f|^2, the pair's curvature numbers s.y, s.s, y.y, the slope g_t.d, and the 17 + 1
+//            inner products of the trial gradient with the basis and with itself;
+//   scalars  accept / backtrack; on acceptance the Gram matrix of the NEW basis follows from those 18 products and
+//            the old matrix by algebra (s_new = alpha d is a combination of the old basis: s_new.b = alpha (B delta),
+//            y_new.b = g_t.b - g.b) -- "vector-free" L-BFGS; then the two-loop recursion on coefficients;
+//   pass 2   commit z, g and the pair, form the next direction and the next trial point.
+// Images of the iteration under L and L^-T (the two-launch slot, see below): f = L z and v = L^-T z = Sigma^-1 f are
+// LINEAR in z, so the trial point's f and v follow from those of the accepted point and of the basis vectors by
+// the same linear combination that forms the trial z -- no product with L or Sigma^-1 per evaluation:
+//   s = zt - z      ->  L s = ft - fz,             L^-T s = vt - vz
+//   g = zt - L^T b  ->  L g = ft - Sigma beta = ft - w,   L^-T g = vt - beta      (b = beta(ft), w from the fused launch)
+//   y = g - g_old   ->  differences of the above
+struct LbImages {
+  double *fz, *ft, *Fd, *FB;      // L z, L zt, L d, L b_l  [LB_NB][N]
+  double *vz, *vt, *Vd, *VB;      // the same under L^-T
+  const double* w;                // Sigma beta(ft)
+};
+
+template <int NT, bool IMG>
+__device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int m, int n_q, double* __restrict__ z,
+                                           double* __restrict__ zt, double* __restrict__ d, const double* u,
+                                           const double* v, const double* beta, const double* tq,
+                                           double* __restrict__ basis, const LbImages& im) {
+  constexpr int HW = (int)(sizeof(WhHead) / 4);
+  constexpr int NA = 7 + LB_NB + 1;      // zz, tsum, gf2, sy, ss, yy, gt.d | gt.b_l | gt.gt
   __shared__ double shB[LB_NB * LB_NB];
-  __shared__ double red[(LB_T / 64) * LB_NB];
-  __shared__ double out[LB_NB];
-  __shared__ double delta[LB_NB];
+  __shared__ double red[(NT / 64) * NA];
+  __shared__ double out[NA];
+  __shared__ double delta[LB_NB];        // coefficients of the direction that produced the trial point (old basis)
+  __shared__ double bdel[LB_NB];         // B delta
   __shared__ double shs[4];
   __shared__ int act[4];
-  if (st->status != 0) return;
+  __shared__ WhHead hs;
   const int tid = threadIdx.x;
-  for (int i = tid; i < LB_NB * LB_NB; i += LB_T) shB[i] = st->B[i];
-  const int first = st->first, need_gf = st->need_gf;
+  if (tid < HW) reinterpret_cast<int*>(&hs)[tid] = reinterpret_cast<const int*>(st)[tid];
+  for (int i = tid; i < LB_NB * LB_NB; i += NT) shB[i] = st->B[i];
+  if (tid < LB_NB) delta[tid] = st->delta[tid];
+  __syncthreads();
+  if (hs.status != 0) return;
+  const int first = hs.first, need_gf = IMG ? 1 : hs.need_gf;     // with the images v = Sigma^-1 f costs nothing
   double* gcur = basis + (size_t)(2 * LB_H) * N;
   const double c1 = 1e-4, c2 = 0.9, eps_f = 1e-13;
-  // ---- pass 1: objective, squared gradient norms, curvature of the would-be pair, slope at the trial point
-  double acc[7] = {0, 0, 0, 0, 0, 0, 0};   // zz, tsum, gf2, sy, ss, yy, gt.d
-  for (int i = tid; i < N; i += LB_T) {
+  // ---- pass 1
+  double acc[NA];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) acc[k] = 0.0;
+  for (int i = tid; i < N; i += NT) {
     const double zi = zt[i], gt = zi - u[i];
     acc[0] += zi * zi;
     if (need_gf) { const double gf = v[i] - beta[i]; acc[2] += gf * gf; }
     if (!first) {
       const double s = zi - z[i], y = gt - gcur[i];
       acc[3] += s * y; acc[4] += s * s; acc[5] += y * y; acc[6] += gt * d[i];
+#pragma unroll
+      for (int l = 0; l < LB_NB; ++l) acc[7 + l] += gt * basis[(size_t)l * N + i];
     }
+    acc[7 + LB_NB] += gt * gt;
   }
-  for (int q = tid; q < n_q; q += LB_T) acc[1] += tq[q];
-  lb_block_sum<7>(acc, red, out);
+  for (int q = tid; q < n_q; q += NT) acc[1] += tq[q];
+  lb_block_sum<NA, NT>(acc, red, out);
+  // ---- the judgement (thread 0)
   if (tid == 0) {
     const double phi_t = 0.5 * out[0] + out[1] / (double)m;
-    const double phi = st->phi, dphi = st->dphi, alpha = st->alpha;
-    const int evals = st->evals + 1;
-    st->evals = evals;
+    const double phi = hs.phi, dphi = hs.dphi, alpha = hs.alpha;
+    hs.evals += 1;
     int a = 1;           // 0 backtrack, 1 accept, 2 restart along steepest descent, 3 stop
     int pair_ok = 0;
     const bool finite = isfinite(phi_t);
@@ -388,143 +444,308 @@ __global__ __launch_bounds__(LB_T) void lbfgs_step_kernel(WhState* __restrict__ 
                                 dphi_t >= c2 * dphi;
       if (!(finite && (armijo || approx_wolfe))) a = 0;
     } else if (!finite) {
-      st->status = 4;
+      hs.status = 4;
       a = 3;
     }
     if (a == 0) {
-      const int ls = st->ls + 1;
-      st->ls = ls;
-      if (evals >= st->max_evals) { st->status = 5; a = 3; }
-      else if (ls > LB_MAX_BACKTRACK) {
-        if (st->hist > 0) {            // forget the history, retry from the accepted point along -g
-          st->hist = 0; st->ls = 0;
+      hs.ls += 1;
+      if (hs.evals >= hs.max_evals) { hs.status = 5; a = 3; }
+      else if (hs.ls > LB_MAX_BACKTRACK) {
+        if (hs.hist > 0) {            // forget the history, retry from the accepted point along -g
+          hs.hist = 0; hs.ls = 0;
           const double gz2 = shB[(2 * LB_H) * LB_NB + 2 * LB_H];
-          st->dphi = -gz2;
-          st->alpha = fmin(1.0, 1.0 / sqrt(gz2));
-          shs[0] = st->alpha;
+          hs.dphi = -gz2;
+          hs.alpha = fmin(1.0, 1.0 / sqrt(gz2));
+          shs[0] = hs.alpha;
           a = 2;
-        } else { st->status = 3; a = 3; }
+        } else { hs.status = 3; a = 3; }
       } else {
         double an = finite ? -dphi * alpha * alpha / (2.0 * (phi_t - phi - dphi * alpha)) : 0.0;
         if (!(an >= 0.1 * alpha)) an = 0.1 * alpha;      // also catches NaN
         if (an > 0.5 * alpha) an = 0.5 * alpha;
-        st->alpha = an;
+        hs.alpha = an;
         shs[0] = an;
       }
     } else if (a == 1) {
       if (!first) {
         pair_ok = out[3] > 1e-10 * sqrt(out[4] * out[5]);
-        st->stall = (phi - phi_t <= 1e-14 * fmax(1.0, fabs(phi))) ? st->stall + 1 : 0;
-        st->iters += 1;
+        hs.stall = (phi - phi_t <= 1e-14 * fmax(1.0, fabs(phi))) ? hs.stall + 1 : 0;
+        hs.iters += 1;
       }
-      st->phi = phi_t;
-      st->ls = 0;
-      if (need_gf) st->gf2 = out[2];
+      hs.phi = phi_t;
+      hs.ls = 0;
+      if (need_gf) hs.gf2 = out[2];
       shs[1] = need_gf ? out[2] : -1.0;
+      shs[2] = alpha;                 // the step length that produced the accepted point
     }
-    act[0] = a; act[1] = pair_ok; act[2] = st->head;
+    act[0] = a; act[1] = pair_ok; act[2] = hs.head;
   }
   __syncthreads();
   const int a = act[0];
-  if (a == 3) return;
-  if (a == 0) {                       // shorter step along the same direction
-    const double an = shs[0];
-    for (int i = tid; i < N; i += LB_T) zt[i] = z[i] + an * d[i];
+  if (a != 1) {
+    if (a == 0) {                     // shorter step along the same direction
+      const double an = shs[0];
+      for (int i = tid; i < N; i += NT) {
+        zt[i] = z[i] + an * d[i];
+        if (IMG) { im.ft[i] = im.fz[i] + an * im.Fd[i]; im.vt[i] = im.vz[i] + an * im.Vd[i]; }
+      }
+    } else if (a == 2) {              // steepest descent from the accepted point
+      const double an = shs[0];
+      for (int i = tid; i < N; i += NT) {
+        const double di = -gcur[i];
+        d[i] = di; zt[i] = z[i] + an * di;
+        if (IMG) {
+          const double fd = -im.FB[(size_t)(2 * LB_H) * N + i], vd = -im.VB[(size_t)(2 * LB_H) * N + i];
+          im.Fd[i] = fd; im.ft[i] = im.fz[i] + an * fd;
+          im.Vd[i] = vd; im.vt[i] = im.vz[i] + an * vd;
+        }
+      }
+      if (tid < LB_NB) st->delta[tid] = (tid == 2 * LB_H) ? -1.0 : 0.0;
+    }
+    if (tid < HW) reinterpret_cast<int*>(st)[tid] = reinterpret_cast<const int*>(&hs)[tid];
     return;
   }
-  if (a == 2) {                       // steepest descent from the accepted point
-    const double an = shs[0];
-    for (int i = tid; i < N; i += LB_T) { const double di = -gcur[i]; d[i] = di; zt[i] = z[i] + an * di; }
-    return;
-  }
-  // ---- accepted: move, store the pair, refresh the Gram rows of what changed
+  // ---- accepted: the Gram matrix of the new basis, by algebra
   const int pair_ok = act[1], r = act[2];
-  for (int i = tid; i < N; i += LB_T) {
-    const double zi = zt[i], gt = zi - u[i];
+  if (tid < LB_NB) {                   // B delta (old matrix, old coefficients)
+    double t = 0.0;
+    for (int mm = 0; mm < LB_NB; ++mm) t += shB[mm * LB_NB + tid] * delta[mm];
+    bdel[tid] = t;
+  }
+  __syncthreads();
+  if (tid < LB_NB) {
+    const int l = tid;
+    const double al = shs[2];
+    const double Gl = out[7 + l];                        // g_t . b_l (old basis; l = 2H: g_t . g_old)
+    const double gtgt = out[7 + LB_NB];
+    const double Gold = shB[(2 * LB_H) * LB_NB + l];      // g_old . b_l
+    double rs = 0.0, ry = 0.0, rg = Gl;                  // rows of s_new, y_new, g_new against entry l
     if (pair_ok) {
-      basis[(size_t)r * N + i] = zi - z[i];
-      basis[(size_t)(LB_H + r) * N + i] = gt - gcur[i];
+      rs = al * bdel[l];
+      ry = Gl - Gold;
+      if (l == r) { rs = out[4]; ry = out[3]; rg = al * out[6]; }                     // against s_new itself
+      else if (l == LB_H + r) { rs = out[3]; ry = out[5]; rg = gtgt - out[7 + 2 * LB_H]; }   // against y_new
+      else if (l == 2 * LB_H) { rs = al * out[6]; ry = gtgt - out[7 + 2 * LB_H]; rg = gtgt; }   // against g_new
+    } else if (l == 2 * LB_H) rg = gtgt;
+    shs[3] = 0.0;
+    // all reads of the old matrix are done (bdel, Gold): write the new rows / columns
+    if (pair_ok) {
+      shB[r * LB_NB + l] = rs;             shB[l * LB_NB + r] = rs;
+      shB[(LB_H + r) * LB_NB + l] = ry;    shB[l * LB_NB + LB_H + r] = ry;
     }
-    gcur[i] = gt;
-    z[i] = zi;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    shB[(2 * LB_H) * LB_NB + l] = rg;      shB[l * LB_NB + 2 * LB_H] = rg;
   }
-  // each thread reads back only elements it wrote itself: no barrier needed before the dots
-  for (int t = 0; t < 3; ++t) {
-    if (t < 2 && !pair_ok) continue;
-    const int tgt = (t == 0) ? r : (t == 1 ? LB_H + r : 2 * LB_H);
-    double dots[LB_NB];
-#pragma unroll
-    for (int l = 0; l < LB_NB; ++l) dots[l] = 0.0;
-    for (int i = tid; i < N; i += LB_T) {
-      const double x = basis[(size_t)tgt * N + i];
-#pragma unroll
-      for (int l = 0; l < LB_NB; ++l) dots[l] += basis[(size_t)l * N + i] * x;
-    }
-    lb_block_sum<LB_NB>(dots, red, out);
-    if (tid < LB_NB) { shB[tgt * LB_NB + tid] = out[tid]; shB[tid * LB_NB + tgt] = out[tid]; }
-    __syncthreads();
-  }
-  // ---- stopping tests and the next direction (scalar work on the Gram matrix)
+  __syncthreads();
+  // ---- stopping tests (thread 0) and the next direction: vector-free two-loop, lane l of wavefront 0 = coefficient l
   if (tid == 0) {
-    int hist = st->hist, head = st->head;
+    int hist = hs.hist, head = hs.head;
     if (pair_ok) { head = (head + 1) % LB_H; hist = hist < LB_H ? hist + 1 : LB_H; }
     const double gz2 = shB[(2 * LB_H) * LB_NB + 2 * LB_H];
-    st->gz2 = gz2;
+    hs.gz2 = gz2;
     int stop = 0;
-    if (shs[1] >= 0.0 && shs[1] < st->gtol2) { st->status = 1; stop = 1; }
-    else if (st->stall >= 3) { st->status = 2; stop = 1; }
-    else if (st->evals >= st->max_evals) { st->status = 5; stop = 1; }
-    else if (!(gz2 > 0.0)) { st->status = isfinite(gz2) ? 1 : 4; stop = 1; }
-    st->need_gf = sqrt(gz2) < st->gate;
-    for (int l = 0; l < LB_NB; ++l) delta[l] = 0.0;
-    double dphi = 0.0;
-    if (!stop) {
-      double al[LB_H];
-      delta[2 * LB_H] = -1.0;
-      for (int k = hist - 1; k >= 0; --k) {               // newest to oldest
-        const int rr = (head - hist + k + 2 * LB_H) % LB_H;
-        double t = 0.0;
-        for (int l = 0; l < LB_NB; ++l) t += delta[l] * shB[l * LB_NB + rr];
-        t /= shB[rr * LB_NB + LB_H + rr];
-        al[k] = t;
-        delta[LB_H + rr] -= t;
-      }
-      if (hist > 0) {
-        const int rn = (head - 1 + LB_H) % LB_H;
-        const double gam = shB[rn * LB_NB + LB_H + rn] / shB[(LB_H + rn) * LB_NB + LB_H + rn];
-        for (int l = 0; l < LB_NB; ++l) delta[l] *= gam;
-      }
-      for (int k = 0; k < hist; ++k) {                    // oldest to newest
-        const int rr = (head - hist + k + 2 * LB_H) % LB_H;
-        double t = 0.0;
-        for (int l = 0; l < LB_NB; ++l) t += delta[l] * shB[l * LB_NB + LB_H + rr];
-        t /= shB[rr * LB_NB + LB_H + rr];
-        delta[rr] += al[k] - t;
-      }
-      for (int l = 0; l < LB_NB; ++l) dphi += delta[l] * shB[l * LB_NB + 2 * LB_H];
-      if (!(dphi < 0.0)) {                                // not a descent direction: drop the history
-        hist = 0;
-        for (int l = 0; l < LB_NB; ++l) delta[l] = 0.0;
-        delta[2 * LB_H] = -1.0;
-        dphi = -gz2;
-      }
-      st->dphi = dphi;
-      st->alpha = first ? fmin(1.0, 1.0 / sqrt(gz2)) : 1.0;
-      shs[0] = st->alpha;
-    }
-    st->hist = hist; st->head = head; st->first = 0;
+    if (shs[1] >= 0.0 && shs[1] < hs.gtol2) { hs.status = 1; stop = 1; }
+    else if (hs.stall >= 3) { hs.status = 2; stop = 1; }
+    else if (hs.evals >= hs.max_evals) { hs.status = 5; stop = 1; }
+    else if (!(gz2 > 0.0)) { hs.status = isfinite(gz2) ? 1 : 4; stop = 1; }
+    hs.need_gf = sqrt(gz2) < hs.gate;
+    hs.hist = hist; hs.head = head; hs.first = 0;
     act[3] = stop;
   }
   __syncthreads();
-  for (int i = tid; i < LB_NB * LB_NB; i += LB_T) st->B[i] = shB[i];
-  if (act[3]) return;
-  const double an = shs[0];
-  for (int i = tid; i < N; i += LB_T) {
-    double di = 0.0;
+  if (!act[3] && tid < 64) {
+    const int l = tid;                                    // all 64 lanes take part in the reductions, l >= LB_NB adds 0
+    const int hist = hs.hist, head = hs.head;
+    const bool live = l < LB_NB;
+    double dl = (l == 2 * LB_H) ? -1.0 : 0.0;
+    double al[LB_H];
 #pragma unroll
-    for (int l = 0; l < LB_NB; ++l) di += delta[l] * basis[(size_t)l * N + i];
-    d[i] = di;
-    zt[i] = z[i] + an * di;
+    for (int k = LB_H - 1; k >= 0; --k) {                 // newest to oldest (unrolled: al[] stays in registers)
+      al[k] = 0.0;
+      if (k >= hist) continue;
+      const int rr = (head - hist + k + 2 * LB_H) % LB_H;
+      double t = wave_sum(live ? dl * shB[l * LB_NB + rr] : 0.0);
+      t /= shB[rr * LB_NB + LB_H + rr];
+      al[k] = t;
+      if (l == LB_H + rr) dl -= t;
+    }
+    if (hist > 0) {
+      const int rn = (head - 1 + LB_H) % LB_H;
+      dl *= shB[rn * LB_NB + LB_H + rn] / shB[(LB_H + rn) * LB_NB + LB_H + rn];
+    }
+#pragma unroll
+    for (int k = 0; k < LB_H; ++k) {                      // oldest to newest
+      if (k >= hist) continue;
+      const int rr = (head - hist + k + 2 * LB_H) % LB_H;
+      double t = wave_sum(live ? dl * shB[l * LB_NB + LB_H + rr] : 0.0);
+      t /= shB[rr * LB_NB + LB_H + rr];
+      if (l == rr) dl += al[k] - t;
+    }
+    double dphi = wave_sum(live ? dl * shB[l * LB_NB + 2 * LB_H] : 0.0);
+    const double gz2 = shB[(2 * LB_H) * LB_NB + 2 * LB_H];
+    if (!(dphi < 0.0)) {                                  // not a descent direction: drop the history
+      dl = (l == 2 * LB_H) ? -1.0 : 0.0;
+      dphi = -gz2;
+      if (l == 0) hs.hist = 0;
+    }
+    if (live) delta[l] = dl;
+    if (l == 0) {
+      hs.dphi = dphi;
+      hs.alpha = first ? fmin(1.0, 1.0 / sqrt(gz2)) : 1.0;
+      shs[0] = hs.alpha;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < LB_NB * LB_NB; i += NT) st->B[i] = shB[i];
+  if (tid < LB_NB) st->delta[tid] = delta[tid];
+  if (tid < HW) reinterpret_cast<int*>(st)[tid] = reinterpret_cast<const int*>(&hs)[tid];
+  // ---- pass 2: commit the point, the gradient and the pair; next direction and trial point
+  const int stop = act[3];
+  const double an = shs[0];
+  for (int i = tid; i < N; i += NT) {
+    const double zi = zt[i], gt = zi - u[i];
+    double bv[LB_NB];
+#pragma unroll
+    for (int l = 0; l < LB_NB; ++l) bv[l] = basis[(size_t)l * N + i];
+    if (pair_ok) {
+      const double sn = zi - z[i], yn = gt - bv[2 * LB_H];
+      basis[(size_t)r * N + i] = sn;
+      basis[(size_t)(LB_H + r) * N + i] = yn;
+#pragma unroll
+      for (int l = 0; l < 2 * LB_H; ++l)
+        if (l == r) bv[l] = sn; else if (l == LB_H + r) bv[l] = yn;
+    }
+    bv[2 * LB_H] = gt;
+    gcur[i] = gt;
+    z[i] = zi;
+    double di = 0.0;
+    if (!stop) {
+#pragma unroll
+      for (int l = 0; l < LB_NB; ++l) di += delta[l] * bv[l];
+      d[i] = di;
+      zt[i] = zi + an * di;
+    }
+    if (IMG) {           // the same commit and the same combination under L and under L^-T
+      const double fti = im.ft[i], vti = im.vt[i];
+      const double fg = fti - im.w[i], vg = vti - beta[i];
+      double fb[LB_NB], vb[LB_NB];
+#pragma unroll
+      for (int l = 0; l < LB_NB; ++l) { fb[l] = im.FB[(size_t)l * N + i]; vb[l] = im.VB[(size_t)l * N + i]; }
+      if (pair_ok) {
+        const double fs = fti - im.fz[i], fy = fg - fb[2 * LB_H], vs = vti - im.vz[i], vy = vg - vb[2 * LB_H];
+        im.FB[(size_t)r * N + i] = fs; im.FB[(size_t)(LB_H + r) * N + i] = fy;
+        im.VB[(size_t)r * N + i] = vs; im.VB[(size_t)(LB_H + r) * N + i] = vy;
+#pragma unroll
+        for (int l = 0; l < 2 * LB_H; ++l) {
+          if (l == r) { fb[l] = fs; vb[l] = vs; }
+          else if (l == LB_H + r) { fb[l] = fy; vb[l] = vy; }
+        }
+      }
+      fb[2 * LB_H] = fg; vb[2 * LB_H] = vg;
+      im.FB[(size_t)(2 * LB_H) * N + i] = fg; im.VB[(size_t)(2 * LB_H) * N + i] = vg;
+      im.fz[i] = fti; im.vz[i] = vti;
+      if (!stop) {
+        double fd = 0.0, vd = 0.0;
+#pragma unroll
+        for (int l = 0; l < LB_NB; ++l) { fd += delta[l] * fb[l]; vd += delta[l] * vb[l]; }
+        im.Fd[i] = fd; im.Vd[i] = vd;
+        im.ft[i] = fti + an * fd;
+        im.vt[i] = vti + an * vd;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(LB_T) void lbfgs_step_kernel(WhState* __restrict__ st, int N, int m, int n_q,
+                                                          double* __restrict__ z, double* __restrict__ zt,
+                                                          double* __restrict__ d, const double* __restrict__ u,
+                                                          const double* __restrict__ v,
+                                                          const double* __restrict__ beta,
+                                                          const double* __restrict__ tq, double* __restrict__ basis) {
+  lbfgs_step<LB_T, false>(st, N, m, n_q, z, zt, d, u, v, beta, tq, basis, LbImages{});
+}
+
+__global__ __launch_bounds__(LB_T) void lbfgs_step_img_kernel(WhState* __restrict__ st, int N, int m, int n_q,
+                                                              double* __restrict__ z, double* __restrict__ zt,
+                                                              double* __restrict__ d, const double* __restrict__ u,
+                                                              const double* __restrict__ beta,
+                                                              const double* __restrict__ tq,
+                                                              double* __restrict__ basis, LbImages im) {
+  lbfgs_step<LB_T, true>(st, N, m, n_q, z, zt, d, u, im.vt, beta, tq, basis, im);
+}
+
+// The fused launch of the two-launch slot: every workgroup rebuilds beta(ft) for itself in LDS (N exponentials --
+// cheaper than a launch), then each wavefront owns one row: u_i = (L^T beta)_i through the row-major copy U of L^T,
+// and w_i = (Sigma beta)_i.  Workgroup 0 publishes beta, the last one the per-query likelihood sums.
+__global__ __launch_bounds__(256) void beta_products_kernel(const WhState* __restrict__ st,
+                                                            const double* __restrict__ ft, int N, int mblk, int n_q,
+                                                            double sigma, const double* __restrict__ U,
+                                                            const double* __restrict__ Sigma,
+                                                            double* __restrict__ beta, double* __restrict__ tq,
+                                                            double* __restrict__ u, double* __restrict__ w) {
+  extern __shared__ __attribute__((aligned(16))) double blds[];     // f [N] | beta [N]
+  if (st->status != 0) return;
+  double* sf = blds;
+  double* sb = blds + N;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int m = mblk - 1;
+  const bool liker = blockIdx.x == gridDim.x - 1;
+  for (int i = threadIdx.x; i < N; i += 256) sf[i] = ft[i];
+  __syncthreads();
+  const double bsc = sigma * (double)m;
+  for (int q = wv; q < n_q; q += 4) {
+    const int i = q * mblk;
+    const double f0 = sf[i];
+    double sp2 = 0.0, sphi = 0.0;
+    for (int r = 1 + lane; r <= m; r += 64) {
+      const double delta = (sf[i + r] - f0) / sigma;
+      const double p2 = INV_SQRT_4PI * exp(-0.25 * (delta * delta));
+      if (liker) sphi += 0.5 * erfc(-0.5 * delta);
+      sp2 += p2;
+      sb[i + r] = -p2 / bsc;
+    }
+    sp2 = wave_sum(sp2);
+    if (liker) sphi = wave_sum(sphi);
+    if (lane == 0) { sb[i] = sp2 / bsc; if (liker) tq[q] = sphi; }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < N; i += 256) beta[i] = sb[i];
+  const int i = blockIdx.x * 4 + wv;
+  if (i >= N) return;
+  const double* ur = U + (size_t)i * N;
+  const double* sr = Sigma + (size_t)i * N;
+  double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
+  // rows are 16-byte aligned (N even is checked by the caller); the triangle of U starts at column i
+  const int k0 = i & ~1;
+  for (int k = 2 * lane; k < N; k += 128) {
+    const double2 b2 = *reinterpret_cast<const double2*>(sb + k);
+    const double2 s2 = *reinterpret_cast<const double2*>(sr + k);
+    c0 += s2.x * b2.x; c1 += s2.y * b2.y;
+    if (k >= k0) {
+      const double2 u2 = *reinterpret_cast<const double2*>(ur + k);
+      a0 += u2.x * b2.x;          // U is zero left of its diagonal
+      a1 += u2.y * b2.y;
+    }
+  }
+  const double su = wave_sum(a0 + a1), sw = wave_sum(c0 + c1);
+  if (lane == 0) { u[i] = su; w[i] = sw; }
+}
+
+// U = L^T (upper triangle written, the rest zero; row pitch N); 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_lower_kernel(const double* __restrict__ L, int N, int ldl,
+                                                              double* __restrict__ U) {
+  __shared__ double t[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;        // tile of L at rows bi*32.., cols bj*32..
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    t[r][tx] = (i < N && j < N && j <= i) ? L[(size_t)i * ldl + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int j = bj * 32 + r, i = bi * 32 + tx;     // U[j][i] = L[i][j]
+    if (i < N && j < N) U[(size_t)j * N + i] = t[tx][r];
   }
 }
 
@@ -881,9 +1102,9 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
   return 0;
 }
 
-int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m,
-                           double sigma, const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
-                           ppbo_fit_stats* h_stats, void* stream) {
+int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma,
+                           const double* d_Sigma_inv, int N, int m, double sigma, const double* d_f_init,
+                           const ppbo_fit_opts* opts, double* d_fMAP, ppbo_fit_stats* h_stats, void* stream) {
   PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_L && d_Sigma_inv && d_f_init && d_fMAP, "null pointer");
   PPBO_REQUIRE(ctx, N > 0 && ldl >= N && m >= 1 && sigma > 0, "sizes");
@@ -915,23 +1136,60 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
   if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, v, zt, 1, 1, s)) return rc;
   PpboGate run; run.skip_if_nonzero = &st->status;
   PpboGate run_gf = run; run_gf.skip_if_zero = &st->need_gf;
-  int batch = 4;
-  for (;;) {
-    for (int k = 0; k < batch; ++k) {
-      if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, zt, ft, 0, 1, s, run)) return rc;                  // f = L zt
-      laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(ft, N, mblk, n_q, sigma, tq, beta, nullptr, nullptr);
-      if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, beta, u, 1, 1, s, run)) return rc;                 // u = L^T beta
-      if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, ft, v, 0, 0, s, run_gf)) return rc;          // v = Sigma^-1 f
-      lbfgs_step_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, v, beta, tq, basis);
+  // ---- two launches per evaluation when Sigma itself is at hand (see LbImages): the fused beta / L^T beta / Sigma beta
+  // kernel and the judgement; otherwise five to six (f = L zt, Laplace terms, L^T beta in two, gated Sigma^-1 f,
+  // judgement).  A dependent launch costs ~8 us on MI355X whatever it does, and these kernels do little.
+  const bool images = d_Sigma != nullptr && (N % 2) == 0 && N <= 8192;
+  LbImages im{};
+  double* U = nullptr;
+  double* wv = nullptr;
+  size_t blds = 0;
+  if (images) {
+    const size_t extra = (size_t)N * N + (size_t)(2 * LB_NB + 8) * N;
+    U = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LBFGS_IMG, extra * sizeof(double));
+    if (!U) return (int)hipErrorOutOfMemory;
+    double* p = U + (size_t)N * N;
+    im.FB = p; p += (size_t)LB_NB * N;
+    im.VB = p; p += (size_t)LB_NB * N;
+    im.fz = p; p += N; im.ft = p; p += N; im.Fd = p; p += N;
+    im.vz = p; p += N; im.vt = p; p += N; im.Vd = p; p += N;
+    wv = p; p += N;
+    im.w = wv;
+    PPBO_HIP_CHECK(ctx, hipMemsetAsync(im.FB, 0, (size_t)2 * LB_NB * N * sizeof(double), s));
+    const int nt32 = (N + 31) / 32;
+    transpose_lower_kernel<<<dim3(nt32, nt32), 256, 0, s>>>(d_L, N, ldl, U);
+    // the first trial point IS the start vector: ft = f_init, vt = Sigma^-1 f_init (= v above), zt = L^T vt (above)
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(im.ft, d_f_init, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(im.vt, v, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    blds = (size_t)2 * N * sizeof(double);
+    if (blds > 48 * 1024) ppbo_lds_limit(ctx, (const void*)beta_products_kernel, 144 * 1024);
+  }
+  auto enqueue_slot = [&]() -> int {
+    if (images) {
+      beta_products_kernel<<<(N + 3) / 4, 256, blds, s>>>(st, im.ft, N, mblk, n_q, sigma, U, d_Sigma, beta, tq, u, wv);
+      lbfgs_step_img_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, beta, tq, basis, im);
+      return 0;
     }
+    if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, zt, ft, 0, 1, s, run)) return rc;                  // f = L zt
+    laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(ft, N, mblk, n_q, sigma, tq, beta, nullptr, nullptr);
+    if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, beta, u, 1, 1, s, run)) return rc;                 // u = L^T beta
+    if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, ft, v, 0, 0, s, run_gf)) return rc;          // v = Sigma^-1 f
+    lbfgs_step_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, v, beta, tq, basis);
+    return 0;
+  };
+  int batch = images ? 8 : 4;
+  for (;;) {
+    for (int k = 0; k < batch; ++k)
+      if (int rc = enqueue_slot()) return rc;
     PPBO_LAUNCH_CHECK(ctx);
     PPBO_HIP_CHECK(ctx, hipMemcpyAsync(hst, st, head_bytes, hipMemcpyDeviceToHost, s));
     PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
     if (verbose)
-      printf("[ppbo_fit whitened] evals %d iters %d phi %.12e |grad_z| %.3e |grad_f| %.3e status %d\n", hst->evals,
-             hst->iters, hst->phi, std::sqrt(hst->gz2), hst->gf2 >= 0 ? std::sqrt(hst->gf2) : -1.0, hst->status);
+      printf("[ppbo_fit whitened%s] evals %d iters %d phi %.12e |grad_z| %.3e |grad_f| %.3e status %d\n",
+             images ? ", 2 launches / evaluation" : "", hst->evals, hst->iters, hst->phi, std::sqrt(hst->gz2),
+             hst->gf2 >= 0 ? std::sqrt(hst->gf2) : -1.0, hst->status);
     if (hst->status != 0) break;
-    if (batch < 8) batch = 8;
+    if (batch < 16) batch *= 2;
   }
   const int lb_status = hst->status, lb_iters = hst->iters, lb_evals = hst->evals;
   if (lb_status == 4) {

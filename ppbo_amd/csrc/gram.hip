@@ -147,7 +147,8 @@ __device__ __forceinline__ double gram_finish(double r2, const KernParams& p, do
 // quarter of the wave's arithmetic and overlap the rest.  HBM-write bound: 8 N^2 + 8 N D bytes.
 template <int KID, int DP>
 __global__ __launch_bounds__(512) void gram_mfma_kernel(const double* __restrict__ X, int N, int D, KernParams p,
-                                                         double shrink, double* __restrict__ Sigma, int nt) {
+                                                         double shrink, double* __restrict__ Sigma, int nt,
+                                                         int order) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int LD = DP + 2;       // 2*odd: fragment reads and panel writes are bank-conflict free
   constexpr int LT = 18;           // transpose strip row pitch (conflict-free b64 writes, 16-byte aligned rows)
@@ -171,6 +172,15 @@ __global__ __launch_bounds__(512) void gram_mfma_kernel(const double* __restrict
     while (bi > 0 && t < bi * n1 - bi * (bi - 1) / 2) --bi;
     while (t >= (bi + 1) * n1 - (bi + 1) * bi / 2) ++bi;
     bj = bi + (t - (bi * n1 - bi * (bi - 1) / 2)) + 1;
+    if (order == 1) {
+      // diagonal-major: the same decomposition read as (distance k = bi + 1 from the diagonal, position r along
+      // it).  Row-major order makes co-resident workgroups share ONE 512-byte column window for their mirror
+      // stores (same bi, consecutive bj): with a power-of-two row pitch those all fall on the same memory
+      // channels.  Along a diagonal both the direct and the mirror windows move with every workgroup.
+      const int k = bi + 1, r = bj - bi - 1;
+      bi = r;
+      bj = r + k;
+    }
   }
   const int i0 = bi * TS, j0 = bj * TS;
 
@@ -301,6 +311,23 @@ __global__ __launch_bounds__(256) void crosscov_kernel(const double* __restrict_
   }
 }
 
+
+// Measurement probe (ppbo_store_floor): a WRITE-ONLY pass over an N x N fp64 matrix, 32 x 128 tiles, 16-byte
+// write-through stores -- the shape tools/store_floor.hip found fastest at HBM-sized N.  It is the ceiling any
+// Gram kernel can reach at that N on this chip; bench.py launches it next to ppbo_gram instead of quoting constants.
+__global__ __launch_bounds__(256) void store_floor_kernel(double* __restrict__ S, int N, double v) {
+  constexpr int TR = 32, TC = 128, LPR = TC / 2, RPP = 256 / LPR;
+  const int ntc = (N + TC - 1) / TC;
+  const int bi = blockIdx.x / ntc, bj = blockIdx.x % ntc;
+  const int c2 = (threadIdx.x % LPR) * 2, r0 = threadIdx.x / LPR;
+#pragma unroll
+  for (int a = 0; a < TR / RPP; ++a) {
+    const int r = bi * TR + a * RPP + r0, c = bj * TC + c2;
+    if (r < N && c + 1 < N) store_through2(S + (size_t)r * N + c, v, v + (double)r);
+    else if (r < N && c < N) S[(size_t)r * N + c] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -318,6 +345,8 @@ int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, con
   hipStream_t s = (hipStream_t)stream;
   ppbo_lds_limit(ctx, (const void*)gram_kernel<PPBO_KERNEL_CAMPHOR>, 112 * 1024);
   PpboProfScope pf(ctx, ppbo_ctx::PF_GRAM, s);
+  // tile order (PPBO_GRAM_VARIANT: 0 row-major over the upper triangle, 1 diagonal-major, -1 = by size)
+  const int order = ctx->gram_variant >= 0 ? ctx->gram_variant : (N >= 4096 ? 1 : 0);
   if (kernel_id != PPBO_KERNEL_CAMPHOR) {
 #define GM_LAUNCH(DPV)                                                                                       \
   do {                                                                                                       \
@@ -326,10 +355,10 @@ int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, con
     const size_t lds = (size_t)body * sizeof(double);                                                        \
     if (kernel_id == PPBO_KERNEL_SE) {                                                                       \
       if (lds > 64 * 1024) ppbo_lds_limit(ctx, (const void*)gram_mfma_kernel<PPBO_KERNEL_SE, DPV>, (int)lds); \
-      gram_mfma_kernel<PPBO_KERNEL_SE, DPV><<<nblk, 512, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);       \
+      gram_mfma_kernel<PPBO_KERNEL_SE, DPV><<<nblk, 512, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt, order);       \
     } else {                                                                                                 \
       if (lds > 64 * 1024) ppbo_lds_limit(ctx, (const void*)gram_mfma_kernel<PPBO_KERNEL_RQ, DPV>, (int)lds); \
-      gram_mfma_kernel<PPBO_KERNEL_RQ, DPV><<<nblk, 512, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);       \
+      gram_mfma_kernel<PPBO_KERNEL_RQ, DPV><<<nblk, 512, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt, order);       \
     }                                                                                                        \
   } while (0)
     if (D <= 4) GM_LAUNCH(4);
@@ -346,6 +375,15 @@ int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, con
     const size_t lds = ((size_t)2 * D * TS + (size_t)TS * TP) * sizeof(double);
     gram_kernel<PPBO_KERNEL_CAMPHOR><<<nblk, 256, lds, s>>>(d_X, N, D, p, shrink, d_Sigma, nt);
   }
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int ppbo_store_floor(ppbo_ctx* ctx, double* d_S, int N, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_S && N > 0 && (N % 2) == 0, "matrix (even N)");
+  const int nt = ((N + 31) / 32) * ((N + 127) / 128);
+  store_floor_kernel<<<nt, 256, 0, (hipStream_t)stream>>>(d_S, N, 1.0);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }

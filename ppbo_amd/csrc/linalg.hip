@@ -834,6 +834,20 @@ __global__ __launch_bounds__(256) void append_border_kernel(const double* __rest
   }
 }
 
+// bordered Cholesky factor: L[n1:, 0:n1] = Y^T, L[n1:, n1:] = L22 (lower), L[0:n1, n1:] = 0
+__global__ __launch_bounds__(256) void append_factor_kernel(const double* __restrict__ Y, const double* __restrict__ L22,
+                                                            int n1, int k, double* __restrict__ L, int ld) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int c = threadIdx.x & 63;
+  if (i >= n1 + k || c >= k) return;
+  if (i < n1) {
+    L[(size_t)(n1 + c) * ld + i] = Y[(size_t)i * k + c];
+    L[(size_t)i * ld + n1 + c] = 0.0;
+  } else {
+    L[(size_t)i * ld + n1 + c] = (c <= i - n1) ? L22[(size_t)(i - n1) * k + c] : 0.0;
+  }
+}
+
 __global__ void set_int_kernel(int* p, int v, double* fail_pivot) {
   *p = v;
   if (fail_pivot) *fail_pivot = NAN;
@@ -1031,8 +1045,15 @@ int ppbo_dgemv(ppbo_ctx* ctx, int trans, int lower, int N, const double* d_A, in
 
 int ppbo_pd_inverse_append(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, const double* d_L11inv,
                            int N1, double* d_Ainv, double* d_Linv, int* h_info, void* stream) {
+  return ppbo_pd_inverse_append_ex(ctx, d_A, N, d_A11inv, d_L11inv, nullptr, N1, d_Ainv, d_Linv, nullptr, h_info, stream);
+}
+
+int ppbo_pd_inverse_append_ex(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, const double* d_L11inv,
+                              const double* d_L11, int N1, double* d_Ainv, double* d_Linv, double* d_L, int* h_info,
+                              void* stream) {
   PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_A && d_A11inv && d_L11inv && d_Ainv && d_Linv && N > 0, "matrix");
+  PPBO_REQUIRE(ctx, (d_L == nullptr) == (d_L11 == nullptr) && (d_L == nullptr || d_L != d_L11), "d_L11 / d_L go together");
   PPBO_REQUIRE(ctx, N1 > 0 && N1 < N && N - N1 <= 64, "append at most 64 rows to a non-empty block");
   PPBO_REQUIRE(ctx, d_Ainv != d_A11inv && d_Linv != d_L11inv, "in-place append is not supported");
   hipStream_t s = (hipStream_t)stream;
@@ -1078,6 +1099,11 @@ int ppbo_pd_inverse_append(ppbo_ctx* ctx, const double* d_A, int N, const double
   PPBO_HIP_CHECK(ctx, hipMemcpy2DAsync(d_Linv, (size_t)N * sizeof(double), d_L11inv, (size_t)N1 * sizeof(double),
                                        (size_t)N1 * sizeof(double), N1, hipMemcpyDeviceToDevice, s));
   append_border_kernel<<<(N + 3) / 4, 256, 0, s>>>(Wm, BR, X, L22i, N1, k, d_Ainv, d_Linv, N);
+  if (d_L) {      // the bordered factor itself: [[L11, 0], [Y^T, L22]]
+    PPBO_HIP_CHECK(ctx, hipMemcpy2DAsync(d_L, (size_t)N * sizeof(double), d_L11, (size_t)N1 * sizeof(double),
+                                         (size_t)N1 * sizeof(double), N1, hipMemcpyDeviceToDevice, s));
+    append_factor_kernel<<<(N + 3) / 4, 256, 0, s>>>(Y, S, N1, k, d_L, N);
+  }
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -66,6 +66,214 @@ __global__ __launch_bounds__(256) void mean_grad_kernel(const double* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Device-resident maximiser of the posterior mean (ppbo_mean_search): what mu_star's differential evolution
+// (gp_model.py:415-437) is replaced by, without a host round trip per iterate.
+//   1. group_max_kernel: the M scored candidates are cut into <= 4096 groups of consecutive rows; each group's best
+//      row survives (the candidates are i.i.d. uniform, so this is a 16-fold thinning, not a loss of coverage).
+//   2. select_starts_kernel (one workgroup): greedy choice of the K best survivors that are pairwise more than
+//      `sep` apart -- argmax, then strike everything within sep of the winner -- the rule the host loop applied.
+//   3. mean_ascent_kernel: one workgroup per start runs the WHOLE projected Barzilai-Borwein ascent: evaluations
+//      of mu and its gradient by all 256 threads (as mean_grad_kernel), the D-vector bookkeeping by wavefront 0 with
+//      lane = coordinate (D <= 64), monotone safeguard, per-start stopping rule.
+
+__global__ __launch_bounds__(256) void group_max_kernel(const double* __restrict__ mu, int64_t M, int G, int T,
+                                                        double* __restrict__ gval, int* __restrict__ gidx) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int64_t lo = (int64_t)t * G, hi = (lo + G < M) ? lo + G : M;
+  double best = -INFINITY;
+  int64_t bi = lo;
+  for (int64_t i = lo; i < hi; ++i) {
+    const double v = mu[i];
+    if (v > best) { best = v; bi = i; }         // NaN never wins
+  }
+  gval[t] = best;
+  gidx[t] = (int)bi;
+}
+
+__global__ __launch_bounds__(1024) void select_starts_kernel(const double* __restrict__ gval,
+                                                             const int* __restrict__ gidx, int T,
+                                                             const double* __restrict__ cand, int D, int K, double sep2,
+                                                             double* __restrict__ starts, int* __restrict__ count) {
+  extern __shared__ double sv[];          // T survivor scores, struck ones at -inf
+  __shared__ double wv[16];
+  __shared__ int wi[16];
+  __shared__ double wpt[64];
+  __shared__ int win;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int t = tid; t < T; t += 1024) sv[t] = gval[t];
+  __syncthreads();
+  int k = 0;
+  for (; k < K; ++k) {
+    double best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int t = tid; t < T; t += 1024) {
+      const double v = sv[t];
+      if (v > best) { best = v; bi = t; }       // ascending t per thread: first index wins
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { wv[wave] = best; wi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      double b = wv[0];
+      int i = wi[0];
+      for (int w = 1; w < 16; ++w)
+        if (wv[w] > b || (wv[w] == b && wi[w] < i)) { b = wv[w]; i = wi[w]; }
+      win = (b > -INFINITY) ? i : -1;
+    }
+    __syncthreads();
+    const int w = win;
+    if (w < 0) break;
+    const double* pw = cand + (size_t)gidx[w] * D;
+    if (tid < D) { const double x = pw[tid]; wpt[tid] = x; starts[(size_t)k * D + tid] = x; }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+      if (!(sv[t] > -INFINITY)) continue;
+      const double* pt = cand + (size_t)gidx[t] * D;
+      double d2 = 0.0;
+      for (int d = 0; d < D; ++d) { const double dx = pt[d] - wpt[d]; d2 += dx * dx; }
+      if (d2 <= sep2) sv[t] = -INFINITY;        // strikes the winner itself too
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *count = k;
+}
+
+// mu and its gradient at the point held in LDS (sx), partial sums of this thread's rows reduced into red[wave][.]
+template <int KID, int DP>
+__device__ __forceinline__ void eval_mean_grad(const double* __restrict__ X, int N, int D, const KernParams& p,
+                                               const double* __restrict__ alpha, const double* sx,
+                                               double (*red)[DP + 1]) {
+  double xc[DP], g[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) { xc[d] = sx[d]; g[d] = 0.0; }
+  double m = 0.0;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const double* __restrict__ xi = X + (size_t)i * D;
+    double dx[DP], s = 0.0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      dx[d] = (d < D) ? xc[d] - xi[d] : 0.0;
+      s += kern_term<KID>(dx[d], d, p);
+    }
+    const double w = alpha[i] * kern_finish<KID>(s, p);
+    m += w;
+    if (KID == PPBO_KERNEL_CAMPHOR) {
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        if (d == 2) g[d] -= 2.0 * p.c1 * dx[d] * w;
+        else if (d < 6) g[d] -= p.c0 * 3.14159265358979323846 * sinpi(2.0 * dx[d]) * w;
+      }
+    } else {
+      const double coef = (KID == PPBO_KERNEL_SE) ? -2.0 * p.c0 * w : -4.0 * p.c0 * w / (1.0 + p.c0 * s);
+#pragma unroll
+      for (int d = 0; d < DP; ++d) g[d] += coef * dx[d];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  m = wave_sum(m);
+#pragma unroll
+  for (int d = 0; d < DP; ++d) g[d] = wave_sum(g[d]);
+  if (lane == 0) {
+    red[wave][DP] = m;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) red[wave][d] = g[d];
+  }
+}
+
+template <int KID, int DP>
+__global__ __launch_bounds__(256) void mean_ascent_kernel(const double* __restrict__ X, int N, int D, KernParams p,
+                                                          const double* __restrict__ alpha,
+                                                          const double* __restrict__ starts,
+                                                          const int* __restrict__ count, int iters, double tol,
+                                                          double* __restrict__ x_out, double* __restrict__ mu_out,
+                                                          int* __restrict__ it_out) {
+  static_assert(DP <= 64, "lane = coordinate");
+  __shared__ double red[4][DP + 1];
+  __shared__ double sx[DP];
+  __shared__ int done;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  if (count && c >= *count) {
+    if (tid == 0) { mu_out[c] = -INFINITY; if (it_out) it_out[c] = 0; }
+    return;
+  }
+  const bool w0 = tid < 64;
+  const int d = tid;                       // coordinate of this lane (wavefront 0 only)
+  const bool live = w0 && d < D;
+  double x = 0.0, g = 0.0, mu = 0.0, step = 0.0, xn = 0.0;
+  if (tid < DP) {
+    x = live ? fmin(fmax(starts[(size_t)c * D + d], 0.0), 1.0) : 0.0;
+    sx[tid] = x;
+  }
+  if (tid == 0) done = 0;
+  __syncthreads();
+  eval_mean_grad<KID, DP>(X, N, D, p, alpha, sx, red);
+  __syncthreads();
+  if (w0) {
+    const int dd = d < DP ? d : DP - 1;
+    g = live ? (red[0][dd] + red[1][dd]) + (red[2][dd] + red[3][dd]) : 0.0;
+    mu = (red[0][DP] + red[1][DP]) + (red[2][DP] + red[3][DP]);
+    const double gn = sqrt(wave_sum(g * g));
+    step = 0.02 / fmax(gn, 1e-300);        // first move: 0.02 in the unit box
+  }
+  int it = 0;
+  for (; it < iters; ++it) {
+    if (w0) {
+      const double pg = ((x <= 0.0 && g < 0.0) || (x >= 1.0 && g > 0.0)) ? 0.0 : g;
+      const double pn = sqrt(wave_sum(pg * pg));
+      if (!(pn * step >= tol)) { if (tid == 0) done = 1; }
+      else {
+        xn = fmin(fmax(x + step * pg, 0.0), 1.0);
+        if (tid < DP) sx[tid] = live ? xn : 0.0;
+      }
+    }
+    __syncthreads();
+    if (done) break;
+    eval_mean_grad<KID, DP>(X, N, D, p, alpha, sx, red);
+    __syncthreads();
+    if (w0) {
+      const int dd = d < DP ? d : DP - 1;
+      const double gnew = live ? (red[0][dd] + red[1][dd]) + (red[2][dd] + red[3][dd]) : 0.0;
+      const double mun = (red[0][DP] + red[1][DP]) + (red[2][DP] + red[3][DP]);
+      const bool ok = mun >= mu;
+      const double sv = live ? xn - x : 0.0, yv = gnew - g;
+      const double curv = -wave_sum(sv * yv);          // > 0 where mu is locally concave along the move
+      const double ss = wave_sum(sv * sv);
+      step = ok ? (curv > 0.0 ? ss / fmax(curv, 1e-300) : 2.0 * step) : 0.25 * step;
+      if (ok) { x = xn; g = gnew; mu = mun; }
+    }
+    // the next write to sx / red happens after every wave has passed the barrier above
+  }
+  if (live) x_out[(size_t)c * D + d] = x;
+  if (tid == 0) { mu_out[c] = mu; if (it_out) it_out[c] = it; }
+}
+
+// out = frac(in + shift): a Cranley-Patterson rotation of a resident uniform candidate pool (keeps it uniform)
+__global__ __launch_bounds__(256) void shift_points_kernel(const double* __restrict__ in, int64_t n, int D,
+                                                           const double* __restrict__ shift,
+                                                           double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double v = in[i] + shift[i % D];
+  out[i] = v - floor(v);
+}
+
+template <int KID>
+void launch_mean_ascent(const ppbo_model* m, const KernParams& p, const double* starts, const int* count, int K,
+                        int iters, double tol, double* x_out, double* mu_out, int* it_out, hipStream_t s) {
+  if (KID == PPBO_KERNEL_CAMPHOR || m->D <= 8)
+    mean_ascent_kernel<KID, 8><<<K, 256, 0, s>>>(m->d_X, m->N, m->D, p, m->d_alpha, starts, count, iters, tol, x_out, mu_out, it_out);
+  else if (m->D <= 24)
+    mean_ascent_kernel<KID, 24><<<K, 256, 0, s>>>(m->d_X, m->N, m->D, p, m->d_alpha, starts, count, iters, tol, x_out, mu_out, it_out);
+  else
+    mean_ascent_kernel<KID, 64><<<K, 256, 0, s>>>(m->d_X, m->N, m->D, p, m->d_alpha, starts, count, iters, tol, x_out, mu_out, it_out);
+}
+
 template <int KID>
 void launch_mean_grad(const ppbo_model* m, const KernParams& p, const double* d_Xc, int M, double* d_mu,
                       double* d_grad, hipStream_t s) {
@@ -96,5 +304,83 @@ extern "C" int ppbo_mean_grad(ppbo_ctx* ctx, const ppbo_model* m, const double* 
     default: launch_mean_grad<PPBO_KERNEL_CAMPHOR>(m, p, d_Xc, (int)M, d_mu, d_grad, s); break;
   }
   PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+
+extern "C" int ppbo_shift_points(ppbo_ctx* ctx, const double* d_in, int64_t M, int D, const double* h_shift,
+                                 double* d_out, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_in && d_out && h_shift && M > 0 && D > 0 && D <= 64, "arguments (D <= 64)");
+  hipStream_t s = (hipStream_t)stream;
+  double* dsh = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH_SMALL, 64 * sizeof(double));
+  if (!dsh) return (int)hipErrorOutOfMemory;
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(dsh, h_shift, (size_t)D * sizeof(double), hipMemcpyHostToDevice, s));
+  const int64_t n = M * D;
+  shift_points_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(d_in, n, D, dsh, d_out);
+  PPBO_LAUNCH_CHECK(ctx);
+  // h_shift is pageable host memory: the copy above is only asynchronous with respect to the DEVICE, the host
+  // buffer has been consumed when hipMemcpyAsync returns
+  return 0;
+}
+
+extern "C" int ppbo_mean_ascent(ppbo_ctx* ctx, const ppbo_model* m, const double* d_starts, int K, int iters,
+                                double tol, double* d_x, double* d_mu, int* d_iters, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, m != nullptr && m->d_X && m->d_alpha, "model X/alpha");
+  PPBO_REQUIRE(ctx, m->N > 0 && m->D > 0 && m->D <= 64, "model sizes (D<=64)");
+  PPBO_REQUIRE(ctx, m->kernel_id >= 0 && m->kernel_id <= 2, "kernel_id");
+  PPBO_REQUIRE(ctx, m->kernel_id != PPBO_KERNEL_CAMPHOR || m->D == 6, "camphor kernel needs D == 6");
+  PPBO_REQUIRE(ctx, d_starts && d_x && d_mu && K > 0 && K <= 65536 && iters >= 0 && tol >= 0, "starts / outputs");
+  hipStream_t s = (hipStream_t)stream;
+  const KernParams p = make_kern_params(m->kernel_id, m->theta);
+  switch (m->kernel_id) {
+    case PPBO_KERNEL_SE: launch_mean_ascent<PPBO_KERNEL_SE>(m, p, d_starts, nullptr, K, iters, tol, d_x, d_mu, d_iters, s); break;
+    case PPBO_KERNEL_RQ: launch_mean_ascent<PPBO_KERNEL_RQ>(m, p, d_starts, nullptr, K, iters, tol, d_x, d_mu, d_iters, s); break;
+    default: launch_mean_ascent<PPBO_KERNEL_CAMPHOR>(m, p, d_starts, nullptr, K, iters, tol, d_x, d_mu, d_iters, s); break;
+  }
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+extern "C" int ppbo_mean_search(ppbo_ctx* ctx, const ppbo_model* m, const double* d_cand, int64_t M, int K, double sep,
+                                int iters, double tol, double* d_x, double* d_mu, int* h_found, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, m != nullptr && m->d_X && m->d_alpha, "model X/alpha");
+  PPBO_REQUIRE(ctx, m->N > 0 && m->D > 0 && m->D <= 64, "model sizes (D<=64)");
+  PPBO_REQUIRE(ctx, m->kernel_id >= 0 && m->kernel_id <= 2, "kernel_id");
+  PPBO_REQUIRE(ctx, m->kernel_id != PPBO_KERNEL_CAMPHOR || m->D == 6, "camphor kernel needs D == 6");
+  PPBO_REQUIRE(ctx, d_cand && d_x && d_mu && M > 0 && M < ((int64_t)1 << 31), "candidates / outputs");
+  PPBO_REQUIRE(ctx, K > 0 && K <= 1024 && sep >= 0 && iters >= 0 && tol >= 0, "K (<= 1024) / sep / iters / tol");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = m->D;
+  const int T_MAX = 4096;
+  const int G = (int)((M + T_MAX - 1) / T_MAX);
+  const int T = (int)((M + G - 1) / G);
+  // workspace: mu[M] | gval[T] | starts[K*D] | gidx[T] (int) | count (int)
+  const size_t nd = (size_t)M + T + (size_t)K * D;
+  double* mu = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH, nd * sizeof(double) + ((size_t)T + 16) * sizeof(int));
+  if (!mu) return (int)hipErrorOutOfMemory;
+  double* gval = mu + M;
+  double* starts = gval + T;
+  int* gidx = (int*)(starts + (size_t)K * D);
+  int* count = gidx + T;
+  ppbo_model mean_only = *m;
+  mean_only.d_G = nullptr;
+  if (int rc = ppbo_predict(ctx, &mean_only, d_cand, M, PPBO_SCORE_MEAN, 0.0, mu, nullptr, nullptr, nullptr, nullptr, stream))
+    return rc;
+  group_max_kernel<<<(T + 255) / 256, 256, 0, s>>>(mu, M, G, T, gval, gidx);
+  select_starts_kernel<<<1, 1024, (size_t)T * sizeof(double), s>>>(gval, gidx, T, d_cand, D, K, sep * sep, starts, count);
+  const KernParams p = make_kern_params(m->kernel_id, m->theta);
+  switch (m->kernel_id) {
+    case PPBO_KERNEL_SE: launch_mean_ascent<PPBO_KERNEL_SE>(m, p, starts, count, K, iters, tol, d_x, d_mu, nullptr, s); break;
+    case PPBO_KERNEL_RQ: launch_mean_ascent<PPBO_KERNEL_RQ>(m, p, starts, count, K, iters, tol, d_x, d_mu, nullptr, s); break;
+    default: launch_mean_ascent<PPBO_KERNEL_CAMPHOR>(m, p, starts, count, K, iters, tol, d_x, d_mu, nullptr, s); break;
+  }
+  PPBO_LAUNCH_CHECK(ctx);
+  if (h_found) {
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(h_found, count, sizeof(int), hipMemcpyDeviceToHost, s));
+    PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  }
   return 0;
 }

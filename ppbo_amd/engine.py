@@ -154,6 +154,12 @@ class Engine:
         self._check(rc, "ppbo_gram")
         return S
 
+    def store_floor(self, out):
+        """Write-only pass over an N x N device matrix (ppbo_store_floor): the Gram kernel's ceiling at that N."""
+        rc = self.lib.ppbo_store_floor(self.ctx, _ptr(out), out.shape[0], self._stream())
+        self._check(rc, "ppbo_store_floor")
+        return out
+
     def cross_cov(self, X1, X2, theta, kernel="SE_kernel"):
         X1, X2 = self.dev(X1), self.dev(X2)
         n1, D = X1.shape
@@ -202,16 +208,34 @@ class Engine:
         self._check(rc, "ppbo_pd_inverse_ex", info.value)
         return out, L
 
-    def pd_inverse_append(self, A, A11inv, L11inv):
-        """(A^-1, L^-1) of A[N,N] given those of its leading N1 x N1 block (one appended query, f-4)."""
+    def pd_inverse_factors3(self, A):
+        """(A^-1, L^-1, L): everything the bordered append extends."""
+        A = self.dev(A)
+        N = A.shape[0]
+        out, linv, L = self.empty(N, N), self.empty(N, N), self.empty(N, N)
+        info = C.c_int(0)
+        rc = self.lib.ppbo_pd_inverse_ex(self.ctx, _ptr(A), N, _ptr(out), _ptr(L), _ptr(linv), C.byref(info), self._stream())
+        self._check(rc, "ppbo_pd_inverse_ex", info.value)
+        return out, linv, L
+
+    def pd_inverse_append(self, A, A11inv, L11inv, L11=None):
+        """(A^-1, L^-1) of A[N,N] given those of its leading N1 x N1 block (one appended query, f-4); with L11 (the
+        factor of that block) the bordered factor L comes back as a third result."""
         A, A11inv, L11inv = self.dev(A), self.dev(A11inv), self.dev(L11inv)
         N, N1 = A.shape[0], A11inv.shape[0]
         out, linv = self.empty(N, N), self.empty(N, N)
         info = C.c_int(0)
-        rc = self.lib.ppbo_pd_inverse_append(self.ctx, _ptr(A), N, _ptr(A11inv), _ptr(L11inv), N1, _ptr(out), _ptr(linv),
-                                             C.byref(info), self._stream())
-        self._check(rc, "ppbo_pd_inverse_append", info.value)
-        return out, linv
+        if L11 is None:
+            rc = self.lib.ppbo_pd_inverse_append(self.ctx, _ptr(A), N, _ptr(A11inv), _ptr(L11inv), N1, _ptr(out),
+                                                 _ptr(linv), C.byref(info), self._stream())
+            self._check(rc, "ppbo_pd_inverse_append", info.value)
+            return out, linv
+        L11 = self.dev(L11)
+        L = self.empty(N, N)
+        rc = self.lib.ppbo_pd_inverse_append_ex(self.ctx, _ptr(A), N, _ptr(A11inv), _ptr(L11inv), _ptr(L11), N1, _ptr(out),
+                                                _ptr(linv), _ptr(L), C.byref(info), self._stream())
+        self._check(rc, "ppbo_pd_inverse_append_ex", info.value)
+        return out, linv, L
 
     def dgemm(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, C_out=None):
         A, B = self.dev(A), self.dev(B)
@@ -272,10 +296,11 @@ class Engine:
         return T.value, grad
 
     def fit_fmap(self, Sigma_inv, f_init, m, sigma, gtol=1e-4, maxiter=0, verbose=False, initial_radius=0.0, L=None,
-                 lbfgs_max_evals=0):
+                 lbfgs_max_evals=0, Sigma=None):
         """f_MAP from one start vector.  L = None: trust-region Newton on f (ppbo_fit_fmap, the reference's
         algorithm class); L = Cholesky factor of Sigma: whitened L-BFGS finished by that trust region
-        (ppbo_fit_fmap_whitened) -- same optimum, tens of O(N^2) evaluations instead of O(N^3) factorizations."""
+        (ppbo_fit_fmap_whitened) -- same optimum, tens of O(N^2) evaluations instead of O(N^3) factorizations.
+        Sigma (optional, with L): two launches per evaluation instead of five to six (see include/ppbo_hip.h)."""
         f0 = self.dev(f_init).reshape(-1)
         N = f0.numel()
         out = self.empty(N)
@@ -286,8 +311,9 @@ class Engine:
                                         _ptr(out), C.byref(st), self._stream())
             self._check(rc, "ppbo_fit_fmap")
         else:
-            rc = self.lib.ppbo_fit_fmap_whitened(self.ctx, _ptr(L), L.stride(0), _ptr(Sigma_inv), N, m, float(sigma),
-                                                 _ptr(f0), C.byref(opts), _ptr(out), C.byref(st), self._stream())
+            rc = self.lib.ppbo_fit_fmap_whitened(self.ctx, _ptr(L), L.stride(0), _ptr(Sigma), _ptr(Sigma_inv), N, m,
+                                                 float(sigma), _ptr(f0), C.byref(opts), _ptr(out), C.byref(st),
+                                                 self._stream())
             self._check(rc, "ppbo_fit_fmap_whitened")
         stats = dict(iterations=st.iterations, n_cholesky=st.n_cholesky, converged=bool(st.converged), T=st.T,
                      gradnorm=st.gradnorm, lbfgs_iterations=st.lbfgs_iterations, lbfgs_evals=st.lbfgs_evals,
@@ -343,6 +369,46 @@ class Engine:
         rc = self.lib.ppbo_mean_grad(self.ctx, C.byref(md), _ptr(Xc), M, _ptr(mu), _ptr(grad), self._stream())
         self._check(rc, "ppbo_mean_grad")
         return mu, grad
+
+    def mean_search(self, post: Posterior, cand, K=32, sep=0.05, iters=100, tol=1e-9):
+        """Device-resident maximiser of the posterior mean over the rows of `cand` (ppbo_mean_search): returns the
+        refined maxima x[found, D], mu[found] as NumPy arrays (one read-back)."""
+        cand = self.dev(cand)
+        M, D = cand.shape
+        md = self._model(post, False)
+        out = self.empty(K, D + 1)                  # [:, :D] points, [:, D] values: one buffer, one copy back
+        x, mu = out[:, :D], out[:, D]
+        xs, mus = self.empty(K, D), self.empty(K)
+        found = C.c_int(0)
+        rc = self.lib.ppbo_mean_search(self.ctx, C.byref(md), _ptr(cand), M, int(K), float(sep), int(iters), float(tol),
+                                       _ptr(xs), _ptr(mus), C.byref(found), self._stream())
+        self._check(rc, "ppbo_mean_search")
+        out[:, :D].copy_(xs)
+        out[:, D].copy_(mus)
+        h = out.cpu().numpy()
+        n = found.value
+        return h[:n, :D].copy(), h[:n, D].copy()
+
+    def mean_ascent(self, post: Posterior, starts, iters=100, tol=1e-9):
+        starts = self.dev(starts)
+        K, D = starts.shape
+        md = self._model(post, False)
+        xs, mus = self.empty(K, D), self.empty(K)
+        its = torch.zeros(K, dtype=torch.int32, device=self.device)
+        rc = self.lib.ppbo_mean_ascent(self.ctx, C.byref(md), _ptr(starts), K, int(iters), float(tol), _ptr(xs), _ptr(mus),
+                                       _ptr(its), self._stream())
+        self._check(rc, "ppbo_mean_ascent")
+        return xs, mus, its
+
+    def shift_points(self, pool, shift, out=None):
+        """out = frac(pool + shift) row-wise (ppbo_shift_points)."""
+        pool = self.dev(pool)
+        M, D = pool.shape
+        out = self.empty(M, D) if out is None else out
+        sh = (C.c_double * D)(*[float(v) for v in shift])
+        rc = self.lib.ppbo_shift_points(self.ctx, _ptr(pool), M, D, sh, _ptr(out), self._stream())
+        self._check(rc, "ppbo_shift_points")
+        return out
 
     def line_acq(self, post: Posterior, grid, z, mustar, shrink=SHRINKAGE, jitter=0.0):
         grid = self.dev(grid)

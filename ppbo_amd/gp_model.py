@@ -26,7 +26,8 @@ from .feedback_processing import FeedbackProcessing
 
 SEARCH_CANDIDATES = 65536      # uniform candidates per mu_star trial
 ASCENT_STARTS = 32             # best well-separated candidates refined together on the device
-ASCENT_ITERS = 100             # cap on batched ascent iterations (one ppbo_mean_grad launch each)
+ASCENT_ITERS = 100             # cap on ascent iterations per start (all inside one mean_ascent_kernel launch)
+POLISH_GRAD_TOL = 1e-6         # |projected grad mu| / |mu| above which mu_star's winner gets the L-BFGS-B polish
 APPEND_REFRESH = 64            # incremental mode: bordered updates of Sigma^-1 between two full inversions (measured:
                                # 32 appends leave |Sigma Sigma^-1 - I| where a full inversion leaves it, 8.2e-8 at N = 2048)
 
@@ -180,20 +181,22 @@ class GPModel:
         th = tuple(float(t) for t in theta)
         st = self._sinv_state
         done = False
-        if (self.incremental and st is not None and self._dLinv is not None and st[1] == th and st[2] < APPEND_REFRESH
-                and 0 < self.N - st[0].shape[0] <= 64 and np.array_equal(self.X[:st[0].shape[0]], st[0])):
+        if (self.incremental and st is not None and self._dLinv is not None and self._dL is not None and st[1] == th
+                and st[2] < APPEND_REFRESH and 0 < self.N - st[0].shape[0] <= 64
+                and np.array_equal(self.X[:st[0].shape[0]], st[0])):
             try:
-                self._dSigma_inv, self._dLinv = self.eng.pd_inverse_append(self._dSigma, self._dSigma_inv, self._dLinv)
+                self._dSigma_inv, self._dLinv, self._dL = self.eng.pd_inverse_append(self._dSigma, self._dSigma_inv,
+                                                                                       self._dLinv, self._dL)
                 self._sinv_state = (self.X.copy(), th, st[2] + 1)
                 self.n_appends += 1
                 done = True
             except NotPositiveDefinite:
                 pass                      # Schur complement lost definiteness to rounding: full inversion below
-        self._dL = None
         if not done:
+            # the Cholesky factor of Sigma comes with the inverse: the whitened f_MAP search and the prior draws use it
             if self.incremental:
-                self._dSigma_inv, self._dLinv = self.eng.pd_inverse_factors(self._dSigma)
-            else:       # the Cholesky factor of Sigma comes with it: the whitened f_MAP search and the prior draws use it
+                self._dSigma_inv, self._dLinv, self._dL = self.eng.pd_inverse_factors3(self._dSigma)
+            else:
                 (self._dSigma_inv, self._dL), self._dLinv = self.eng.pd_inverse_chol(self._dSigma), None
             self._sinv_state = (self.X.copy(), th, 0)
             self.n_full_inversions += 1
@@ -306,7 +309,7 @@ class GPModel:
             Sinv, L = eng.pd_inverse_chol(Sig)
         else:
             Sinv, L = eng.pd_inverse(Sig), None
-        fm, st = eng.fit_fmap(Sinv, f0, self.m, theta[0], gtol=1e-4, maxiter=500, L=L)
+        fm, st = eng.fit_fmap(Sinv, f0, self.m, theta[0], gtol=1e-4, maxiter=500, L=L, Sigma=Sig)
         _, _, ld, lo = eng.laplace_terms(fm, self.m, theta[0])
         sgn, logdet, _ = eng.laplace_logdet(Sig, ld, lo, self.m)
         log_evidence = st["T"] - 0.5 * sgn * logdet
@@ -438,7 +441,8 @@ class GPModel:
         # independent restarts (the reference's 10 on the last iteration, gp_model.py:96-97) run concurrently
         t_fit = time.time()
         L = self._dL if self.fMAP_method == "whitened" else None
-        jobs = [(lambda eng, f0=f0: eng.fit_fmap(self._dSigma_inv, f0, self.m, self.theta[0], gtol=gtol, L=L))
+        jobs = [(lambda eng, f0=f0: eng.fit_fmap(self._dSigma_inv, f0, self.m, self.theta[0], gtol=gtol, L=L,
+                                                 Sigma=self._dSigma))
                 for f0 in starts]
         results = self._run_concurrently(jobs, self._default_workers(self.N) if trials > 1 else 1)
         t_fit = (time.time() - t_fit) / max(trials, 1)
@@ -447,7 +451,7 @@ class GPModel:
                 import torch
                 fm.record_stream(torch.cuda.current_stream(self.eng.device))
             self.fit_log.append(dict(N=self.N, iterations=st["iterations"], n_cholesky=st["n_cholesky"],
-                                     lbfgs_evals=st["lbfgs_evals"], lbfgs_status=st["lbfgs_status"],
+                                     lbfgs_evals=st.get("lbfgs_evals", 0), lbfgs_status=st.get("lbfgs_status", -1),
                                      converged=st["converged"], warm=bool(warm), seconds=t_fit))
             if (self.fMAP_restart_on_stall and not st["converged"] and not approx_optimization
                     and st["gradnorm"] > 1e3 * gtol):
@@ -456,7 +460,8 @@ class GPModel:
                 # descent predicted / radius collapsed): the reference hands back SciPy's last iterate
                 # (gp_model.py:382-389); with the flag set, one fresh start from the prior is tried as well
                 print("---!!!--- f_MAP search stopped at |grad T| = " + str(st["gradnorm"]) + "; restarting from a prior draw")
-                fm2, st2 = self.eng.fit_fmap(self._dSigma_inv, self._draw_prior(), self.m, self.theta[0], gtol=gtol, L=L)
+                fm2, st2 = self.eng.fit_fmap(self._dSigma_inv, self._draw_prior(), self.m, self.theta[0], gtol=gtol, L=L,
+                                             Sigma=self._dSigma)
                 if st2["T"] > st["T"] or not np.isfinite(st["T"]):
                     fm, st = fm2, st2
             if self.verbose:
@@ -554,31 +559,11 @@ class GPModel:
 
     # ------------------------------------------------------------------ maximiser of the posterior mean
     def _ascend(self, starts):
-        """Batched projected gradient ascent on the posterior mean from K starts at once: Barzilai-Borwein
-        step lengths per start, monotone safeguard (a start only moves when mu does not drop), one
-        ppbo_mean_grad launch for all starts per iteration.  SURVEY 8(f) f-2."""
-        post = self._mean_post()
-        x = np.clip(np.atleast_2d(starts).astype(float), 0.0, 1.0)
-        mu_t, g_t = self.eng.mean_grad(post, x)
-        mu, g = mu_t.cpu().numpy(), g_t.cpu().numpy()
-        gn = np.linalg.norm(g, axis=1)
-        step = 0.02 / np.maximum(gn, 1e-300)                  # first move: 0.02 in the unit box
-        for _ in range(ASCENT_ITERS):
-            pg = np.where(((x <= 0.0) & (g < 0.0)) | ((x >= 1.0) & (g > 0.0)), 0.0, g)
-            if np.max(np.linalg.norm(pg, axis=1) * step) < 1e-9:
-                break
-            xn = np.clip(x + step[:, None] * pg, 0.0, 1.0)
-            mun_t, gn_t = self.eng.mean_grad(post, xn)
-            mun, gnew = mun_t.cpu().numpy(), gn_t.cpu().numpy()
-            ok = mun >= mu
-            sv, yv = xn - x, gnew - g
-            curv = -(sv * yv).sum(axis=1)                     # > 0 where mu is locally concave along the move
-            bb = (sv * sv).sum(axis=1) / np.maximum(curv, 1e-300)
-            step = np.where(ok, np.where(curv > 0.0, bb, 2.0 * step), 0.25 * step)
-            x = np.where(ok[:, None], xn, x)
-            g = np.where(ok[:, None], gnew, g)
-            mu = np.where(ok, mun, mu)
-        return x, mu
+        """Projected gradient ascent on the posterior mean from K starts at once (ppbo_mean_ascent: Barzilai-Borwein
+        step lengths, monotone safeguard, the whole iteration of a start inside one workgroup).  SURVEY 8(f) f-2."""
+        xs, mus, _ = self.eng.mean_ascent(self._mean_post(), np.clip(np.atleast_2d(starts).astype(float), 0.0, 1.0),
+                                          iters=ASCENT_ITERS, tol=1e-9)
+        return xs.cpu().numpy(), mus.cpu().numpy()
 
     def _polish(self, x0):
         """Bounded quasi-Newton polish of one point with the analytic device gradient."""
@@ -592,35 +577,55 @@ class GPModel:
                                       options={"maxiter": 200, "ftol": 1e-15, "gtol": 1e-10})
         return np.clip(res.x, 0.0, 1.0), -float(res.fun)
 
+    def _candidate_pool(self):
+        """SEARCH_CANDIDATES uniform points, drawn ONCE from the global NumPy stream and kept resident in HBM; every
+        mu_star trial sees them through a fresh random rotation frac(pool + shift) (ppbo_shift_points), which
+        keeps them uniform -- instead of generating and uploading 65536 x D numbers per trial."""
+        pool = self.__dict__.get("_pool")
+        if pool is None or pool.shape[1] != self.D:
+            pool = self.eng.dev(np.random.uniform(0.0, 1.0, (SEARCH_CANDIDATES, self.D)))
+            self._pool = pool
+        return pool
+
     def mu_star(self, mustar_finding_trials=None):
-        """argmax of the posterior mean (gp_model.py:415-437).  The reference runs SciPy differential
-        evolution `trials` times; here every trial scores 65536 candidates in one launch, refines the
-        ASCENT_STARTS best well-separated ones together by gradient ascent on the device, and polishes the
-        winner.  All distinct converged maxima feed xstars_local (gp_model.py:430-431)."""
+        """argmax of the posterior mean (gp_model.py:415-437).  The reference runs SciPy differential evolution
+        `trials` times (2 k ... 17 k sequential mu_pred calls each); here a trial is ONE device enqueue
+        (ppbo_mean_search): score 65536 rotated pool candidates plus the design points and the previous x*, keep the
+        ASCENT_STARTS best that are > 0.05 apart, run the whole Barzilai-Borwein ascent of each inside one kernel;
+        the host reads ASCENT_STARTS x (D + 1) numbers back and polishes the winner.  All distinct converged maxima
+        feed xstars_local (gp_model.py:430-431)."""
+        import torch
         trials = self.mustar_finding_trials if mustar_finding_trials is None else mustar_finding_trials
-        D = self.D
+        D, N = self.D, self.N
+        post = self._mean_post()
+        pool = self._candidate_pool()
+        M = pool.shape[0]
+        work = torch.empty((M + N + 1, D), dtype=torch.float64, device=self.eng.device)
+        work[M:M + N].copy_(self._dX)                                  # the design points themselves
+        work[M + N].copy_(self.eng.dev(self.xstar if self.xstar is not None else self.X[0]))
         found = []
         for t in range(trials):
-            cand = np.random.uniform(0.0, 1.0, (SEARCH_CANDIDATES, D))
-            if t == 0:
-                k = min(self.N, SEARCH_CANDIDATES // 2)
-                cand[:k] = self.X[np.random.permutation(self.N)[:k]]      # the design points themselves
-                if self.xstar is not None:
-                    cand[k] = self.xstar
-            mu_c = self.mu_pred_batch(cand)
-            order = np.argsort(-mu_c)[:4096]
-            starts = []
-            for i in order:                                               # greedy: best first, > 0.05 apart
-                if all(np.linalg.norm(cand[i] - y) > 5e-2 for y in starts):
-                    starts.append(cand[i])
-                    if len(starts) == ASCENT_STARTS:
-                        break
-            xs, vals = self._ascend(np.vstack(starts))
+            self.eng.shift_points(pool, np.random.uniform(0.0, 1.0, D), out=work[:M])
+            # the design points (where f_MAP's maxima sit) and the previous x* join the first trial only: they would
+            # claim the same ASCENT_STARTS basins in every trial and leave the uniform candidates' basins unexplored
+            xs, vals = self.eng.mean_search(post, work if t == 0 else work[:M], K=ASCENT_STARTS, sep=5e-2,
+                                            iters=ASCENT_ITERS, tol=1e-9)
+            if len(vals) == 0:
+                continue
             best = int(np.argmax(vals))
-            xp, vp = self._polish(xs[best])
-            if vp >= vals[best]:
-                xs[best], vals[best] = xp, vp
+            # the ascent stops on |projected gradient| * step < 1e-9; the quasi-Newton polish (a device round trip
+            # per function value) is only worth its milliseconds when the winner is NOT yet stationary
+            _, gb = self.eng.mean_grad(post, xs[best][None, :])
+            gb = gb.cpu().numpy()[0]
+            pg = np.where(((xs[best] <= 0.0) & (gb < 0.0)) | ((xs[best] >= 1.0) & (gb > 0.0)), 0.0, gb)
+            if np.abs(pg).max() > POLISH_GRAD_TOL * max(abs(vals[best]), 1e-300):
+                xp, vp = self._polish(xs[best])
+                if vp >= vals[best]:
+                    xs[best], vals[best] = xp, vp
             found.extend(zip(vals.tolist(), xs))
+        if not found:                 # no finite mean anywhere (cannot happen with a fitted model): keep the old x*
+            x0 = self.xstar if self.xstar is not None else self.X[0]
+            return np.asarray(x0, dtype=float).reshape(D,), self.mu_pred(x0), np.asarray(x0, dtype=float).reshape(1, D)
         found.sort(key=lambda p: -p[0])
         xstar = found[0][1].copy()
         local = [found[0][1]]

@@ -26,11 +26,19 @@ def test_bordered_inverse_matches_full_inverse(eng, golden, name):
     n_q = N // mb
     q0 = max(1, n_q // 2)
     Xd = eng.dev(X)
-    Sinv, Linv = eng.pd_inverse_factors(eng.gram(Xd[:q0 * mb], th, kern))
+    Sinv, Linv, L = eng.pd_inverse_factors3(eng.gram(Xd[:q0 * mb], th, kern))
     for q in range(q0, n_q):
         Sig = eng.gram(Xd[:(q + 1) * mb], th, kern)
-        Sinv, Linv = eng.pd_inverse_append(Sig, Sinv, Linv)
-    full, Lfull = eng.pd_inverse_factors(Sig)
+        if q % 2:                                    # both entry points: with and without the bordered factor
+            Sinv, Linv, L = eng.pd_inverse_append(Sig, Sinv, Linv, L)
+        else:
+            Sinv2, Linv2 = eng.pd_inverse_append(Sig, Sinv, Linv)
+            Sinv, Linv, L = eng.pd_inverse_append(Sig, Sinv, Linv, L)
+            assert np.array_equal(Sinv.cpu().numpy(), Sinv2.cpu().numpy())
+    full, Lfull, Lfac = eng.pd_inverse_factors3(Sig)
+    Lh, Lfh = np.tril(L.cpu().numpy()), np.tril(Lfac.cpu().numpy())
+    assert np.abs(Lh - Lfh).max() <= 1e-8 * np.abs(Lfh).max()           # ... and is the factor of the new matrix
+    assert np.abs(Lh @ Lh.T - Sig.cpu().numpy()).max() <= 1e-12 * np.abs(Lfh).max() ** 2
     Sg, A, B = Sig.cpu().numpy(), Sinv.cpu().numpy(), full.cpu().numpy()
     I = np.eye(N)
     res_app, res_full = np.abs(Sg @ A - I).max(), np.abs(Sg @ B - I).max()
@@ -43,10 +51,12 @@ def test_bordered_inverse_matches_full_inverse(eng, golden, name):
     a_app, a_full = A @ f, B @ f
     assert np.abs(a_app - a_full).max() <= 1e-6 * np.abs(a_full).max()
     assert np.abs(A - A.T).max() <= 1e-9 * np.abs(A).max()
-    # and the fit started from the same vector lands on the same f_MAP
+    # and the fit started from the same vector lands on the same f_MAP, on either path
     f1, _ = eng.fit_fmap(Sinv, g["f_init"], m, th[0], gtol=1e-6)
     f2, _ = eng.fit_fmap(full, g["f_init"], m, th[0], gtol=1e-6)
     assert np.abs(f1.cpu().numpy() - f2.cpu().numpy()).max() <= 1e-5 * np.abs(g["fMAP"]).max()
+    f3, s3 = eng.fit_fmap(Sinv, g["f_init"], m, th[0], gtol=1e-6, L=L)
+    assert s3["lbfgs_evals"] > 0 and np.abs(f3.cpu().numpy() - f2.cpu().numpy()).max() <= 1e-5 * np.abs(g["fMAP"]).max()
 
 
 def test_append_rejects_bad_arguments(eng):
@@ -65,7 +75,7 @@ def test_append_reports_indefinite_border(eng):
         eng.pd_inverse_append(eng.dev(A), eng.dev(np.eye(4)), eng.dev(np.eye(4)))
 
 
-def _replay(golden, incremental):
+def _replay(golden, incremental, method="whitened"):
     """Feed the reference's own C1 queries (fixture g7) to the drop-in, one at a time.  The global NumPy stream is
     re-seeded before every design update and every fit, so cold and incremental runs see identical designs."""
     from ppbo_amd.gp_model import GPModel
@@ -74,6 +84,7 @@ def _replay(golden, incremental):
     st = PPBO_settings(D=2, bounds=tuple(map(tuple, g["bounds"])), xi_acquisition_function="PCD", m=int(g["m"]),
                        theta_initial=list(map(float, g["theta"])), verbose=False)
     gp = GPModel(st, incremental=incremental)
+    gp.fMAP_method = method
     n_init = int(g["n_init"])
     out = []
     for i in range(g["X_obs"].shape[0]):
@@ -90,18 +101,21 @@ def _replay(golden, incremental):
         gap = float(np.abs(gp.posterior_covariance @ grad.cpu().numpy()).max()) if i >= n_init - 1 else np.inf
         out.append(dict(N=gp.N, fMAP=gp.fMAP.copy(), mustar=gp.mustar, xstar=gp.xstar.copy(), gap=gap,
                         chol=sum(t["n_cholesky"] for t in gp.fit_log[n_log:]),
+                        evals=sum(t["lbfgs_evals"] for t in gp.fit_log[n_log:]),
                         iters=sum(t["iterations"] for t in gp.fit_log[n_log:]), X=gp.X.copy(),
                         n_appends=gp.n_appends, n_full=gp.n_full_inversions,
                         sinv_res=float(np.abs(gp.Sigma @ gp.Sigma_inv - np.eye(gp.N)).max())))
     return g, out
 
 
-def test_incremental_replay_matches_cold_refits(golden):
+@pytest.mark.parametrize("method", ["whitened", "trust-region"])
+def test_incremental_replay_matches_cold_refits(golden, method):
     """Same queries and designs, cold (a prior draw per update, the reference's default) vs incremental (bordered
-    Sigma^-1, warm start), both at the reference's stopping rule: the same f_MAP to 1e-5 max|f| plus the two fits'
-    own Newton gaps, the same mu*, and >= 3x fewer factorizations per query."""
-    g, cold = _replay(golden, False)
-    g, inc = _replay(golden, True)
+    Sigma^-1 / L^-1 / L, warm start), both at the reference's stopping rule: the same f_MAP to 1e-5 max|f| plus the
+    two fits' own Newton gaps, the same mu*, and markedly less work per query: >= 3x fewer factorizations on the
+    trust-region path, >= 1.5x fewer O(N^2) evaluations (and still no factorization) on the whitened path."""
+    g, cold = _replay(golden, False, method)
+    g, inc = _replay(golden, True, method)
     n_init = int(g["n_init"])
     ratio, worst = [], 0.0
     # the model-level path really borders Sigma^-1 (one append per query after the first full inversion) ...
@@ -118,10 +132,16 @@ def test_incremental_replay_matches_cold_refits(golden):
         assert df <= 1e-5 * scale + 1.5 * (cold[i]["gap"] + inc[i]["gap"]), (i, cold[i]["N"], df, cold[i]["gap"], inc[i]["gap"])
         worst = max(worst, df / scale)
         assert abs(cold[i]["mustar"] - inc[i]["mustar"]) <= 1e-4 * max(abs(cold[i]["mustar"]), 1e-3)
-        ratio.append(cold[i]["chol"] / max(inc[i]["chol"], 1))
-    print("factorizations per query cold/incremental:", [(c["chol"], k["chol"]) for c, k in zip(cold[n_init:], inc[n_init:])])
+        key = "chol" if method == "trust-region" else "evals"
+        ratio.append(cold[i][key] / max(inc[i][key], 1))
+    print(f"{method}: factorizations per query cold/incremental:", [(c["chol"], k["chol"]) for c, k in zip(cold[n_init:], inc[n_init:])])
+    print(f"{method}: L-BFGS evaluations per query cold/incremental:", [(c["evals"], k["evals"]) for c, k in zip(cold[n_init:], inc[n_init:])])
     print(f"worst |f_cold - f_inc| / max|f| = {worst:.2e}")
-    assert np.median(ratio) >= 3.0, ratio
+    if method == "trust-region":
+        assert np.median(ratio) >= 3.0, ratio
+    else:
+        assert np.median(ratio) >= 1.5, ratio
+        assert max(k["chol"] for k in inc[n_init:]) <= 2
 
 
 def test_incremental_switched_on_late_falls_back_to_full_inversion(golden):

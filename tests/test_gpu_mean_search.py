@@ -1,0 +1,123 @@
+"""f-2 device-resident: ppbo_mean_ascent / ppbo_mean_search / ppbo_shift_points -- the maximiser of the posterior
+mean that replaces mu_star's differential evolution (src/gp_model.py:415-437) -- against the oracle's mean and
+gradient, and timed per trial on the C2 shape."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import ppbo_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from ppbo_amd.engine import get_engine
+    return get_engine(0)
+
+
+def _post(eng, g):
+    from test_gpu_parity import _posterior
+    return _posterior(eng, g)[0]
+
+
+def _proj(x, g):
+    return np.where(((x <= 0) & (g < 0)) | ((x >= 1) & (g > 0)), 0.0, g)
+
+
+@pytest.mark.parametrize("name", ["smoke", "rq", "cam_small", "c2", "c3"])
+def test_ascent_climbs_to_stationary_points(eng, golden, name):
+    g = golden(name)
+    post = _post(eng, g)
+    D = g["X"].shape[1]
+    rng = np.random.default_rng(5)
+    starts = np.vstack([rng.random((24, D)), g["X"][:8]])
+    alpha = host(post.alpha)
+    mu0, g0 = orc.mean_grad(starts, g["X"], g["theta"], alpha, str(g["kernel"]))
+    xs, mus, its = eng.mean_ascent(post, starts, iters=100, tol=1e-9)
+    xs, mus, its = host(xs), host(mus), host(its)
+    assert np.all((xs >= 0) & (xs <= 1)) and np.all(its <= 100)
+    assert np.all(mus >= mu0 - 1e-12 * np.abs(mu0).max()), "monotone safeguard"
+    mu1, g1 = orc.mean_grad(xs, g["X"], g["theta"], alpha, str(g["kernel"]))
+    assert np.abs(mu1 - mus).max() <= 1e-9 * np.abs(mu1).max() + 1e-14            # the value IS the mean there
+    # most starts end (near-)stationary: the projected gradient has dropped by orders of magnitude
+    drop = np.abs(_proj(xs, g1)).max(axis=1) / (np.abs(_proj(starts, g0)).max(axis=1) + 1e-300)
+    assert np.median(drop) < 1e-2, drop
+    # a second call continues from there without losing anything, and zero iterations is the identity
+    xs2, mus2, _ = eng.mean_ascent(post, xs, iters=100, tol=1e-9)
+    assert np.all(host(mus2) >= mus - 1e-12 * np.abs(mus).max())
+    xs0, mus0, its0 = eng.mean_ascent(post, starts, iters=0)
+    assert np.array_equal(host(xs0), np.clip(starts, 0, 1)) and np.all(host(its0) == 0)
+    assert np.abs(host(mus0) - mu0).max() <= 1e-9 * np.abs(mu0).max() + 1e-14
+
+
+def test_shift_points_is_a_rotation_of_the_unit_box(eng):
+    rng = np.random.default_rng(1)
+    P = rng.random((1000, 7))
+    sh = rng.random(7)
+    out = host(eng.shift_points(P, sh))
+    ref = (P + sh) - np.floor(P + sh)
+    assert np.array_equal(out, ref) and np.all((out >= 0) & (out < 1))
+
+
+@pytest.mark.parametrize("name", ["smoke", "c2", "c3"])
+def test_mean_search_finds_the_best_candidate_and_more(eng, golden, name):
+    """The refined maxima are at least as high as the best raw candidate, the winner is a stationary point, and on
+    the reference's own fixtures the search reaches the maximum differential evolution reported."""
+    from conftest import load_golden
+    g = golden(name)
+    x = load_golden(name + "_x")
+    post = _post(eng, g)
+    D = g["X"].shape[1]
+    rng = np.random.default_rng(9)
+    cand = np.vstack([rng.random((20000, D)), g["X"]])
+    alpha = host(post.alpha)
+    mu_c, g_c = orc.mean_grad(cand[:4000], g["X"], g["theta"], alpha, str(g["kernel"]))
+    xs, vals = eng.mean_search(post, cand, K=32, sep=0.05, iters=100, tol=1e-9)
+    assert 1 <= len(vals) <= 32 and xs.shape == (len(vals), D)
+    assert vals.max() >= mu_c.max() - 1e-12
+    mu1, g1 = orc.mean_grad(xs, g["X"], g["theta"], alpha, str(g["kernel"]))
+    assert np.abs(mu1 - vals).max() <= 1e-9 * np.abs(mu1).max() + 1e-14
+    b = int(np.argmax(vals))
+    assert np.abs(_proj(xs[b], g1[b])).max() <= 1e-3 * np.abs(g_c).max() + 1e-9     # vs the gradient scale of raw candidates
+    assert vals.max() >= float(x["mustar"]) - 1e-4 * abs(float(x["mustar"]))       # DE's maximum (polish closes the rest)
+
+
+def test_mean_search_handles_few_and_clustered_candidates(eng, golden):
+    g = golden("smoke")
+    post = _post(eng, g)
+    D = g["X"].shape[1]
+    one = np.full((1, D), 0.5)
+    xs, vals = eng.mean_search(post, one, K=8)
+    assert len(vals) == 1
+    same = np.tile(one, (500, 1)) + 1e-4 * np.random.default_rng(0).standard_normal((500, D))
+    xs, vals = eng.mean_search(post, same, K=8, sep=0.05)
+    assert len(vals) == 1                      # everything within `sep` of the winner is struck
+    with pytest.raises(RuntimeError):
+        eng.mean_search(post, one, K=5000)
+
+
+def test_mu_star_per_trial_time_at_c2(golden):
+    """mu_star <= 3 ms per trial at C2 (N = 512, D = 6), same quality bar as
+    test_mu_star_vs_reference_differential_evolution."""
+    import torch
+    from conftest import load_golden
+    from test_gpu_golden_r2 import _fitted
+    x = load_golden("c2_x")
+    g, gp, st = _fitted(golden, "c2")
+    np.random.seed(40)
+    gp.mu_star(mustar_finding_trials=1)        # warm: pool upload, workspaces
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    trials = 10
+    xstar, mustar, local = gp.mu_star(mustar_finding_trials=trials)
+    torch.cuda.synchronize()
+    per_trial = (time.perf_counter() - t0) * 1e3 / trials
+    print(f"mu_star at C2: {per_trial:.2f} ms per trial; mustar {mustar:.9f} (DE: {float(x['mustar']):.9f}), {len(local)} local maxima")
+    assert mustar >= float(x["mustar"]) - 1e-6 * abs(float(x["mustar"]))
+    assert per_trial <= 3.0

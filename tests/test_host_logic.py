@@ -74,10 +74,11 @@ def test_settings_derivations():
     assert s.fMAP_optimizer == "trust-exact" and s.mc_samples == 150 and s.n_gausshermite_sample_points == 200
 
 
-def test_batched_ascent_and_polish_host_logic():
-    """GPModel._ascend / _polish (the host half of mu_star's refinement) driven by a stand-in engine whose
-    mean_grad is the oracle's: every start must climb monotonically to a stationary point of mu inside the box,
-    and the polish must not lose value.  (The device kernel itself is checked in test_gpu_parity.py.)"""
+def test_polish_host_logic():
+    """GPModel._polish (the host half of mu_star's refinement: bounded L-BFGS-B on the device's mean + gradient)
+    driven by a stand-in engine whose mean_grad is the oracle's: it must not lose value and must end on a
+    stationary point of mu inside the box.  (The device-resident ascent and search are checked in
+    tests/test_gpu_mean_search.py.)"""
     import torch
     from oracle import ppbo_oracle as orc
     from ppbo_amd.gp_model import GPModel
@@ -96,21 +97,16 @@ def test_batched_ascent_and_polish_host_logic():
     gp = object.__new__(GPModel)
     gp.eng, gp.D, gp.bounds, gp._post_mean = Eng(), D, ((0, 1),) * D, object()
     starts = rng.random((12, D))
+    for _ in range(200):            # the polish is applied to the ascent's output: get near a maximum first
+        _, g0 = orc.mean_grad(starts, X, theta, alpha)
+        starts = np.clip(starts + 0.002 * g0 / max(np.abs(g0).max(), 1e-300) * 5.0, 0.0, 1.0)
     mu0, _ = orc.mean_grad(starts, X, theta, alpha)
-    xs, vals = gp._ascend(starts)
-    assert xs.shape == starts.shape and np.all((xs >= 0) & (xs <= 1))
-    assert np.all(vals >= mu0 - 1e-12)
-    mu1, g1 = orc.mean_grad(xs, X, theta, alpha)
-    assert np.allclose(mu1, vals, rtol=0, atol=1e-12)
-    pg = np.where(((xs <= 0) & (g1 < 0)) | ((xs >= 1) & (g1 > 0)), 0.0, g1)
-    best = int(np.argmax(vals))
-    xp, vp = gp._polish(xs[best])
-    assert vp >= vals[best] - 1e-12 and np.all((xp >= 0) & (xp <= 1))
-    _, gp_ = orc.mean_grad(xp[None, :], X, theta, alpha)
-    pgp = np.where(((xp <= 0) & (gp_[0] < 0)) | ((xp >= 1) & (gp_[0] > 0)), 0.0, gp_[0])
-    assert np.abs(pgp).max() < 1e-5 * max(1.0, np.abs(alpha).max())
-    # most starts are already close to stationary after the batched ascent
-    assert np.median(np.abs(pg).max(axis=1)) < 1e-2 * np.abs(g1).max() + 1e-6
+    for k in range(len(starts)):
+        xp, vp = gp._polish(starts[k])
+        assert vp >= mu0[k] - 1e-12 and np.all((xp >= 0) & (xp <= 1))
+        _, gp_ = orc.mean_grad(xp[None, :], X, theta, alpha)
+        pgp = np.where(((xp <= 0) & (gp_[0] < 0)) | ((xp >= 1) & (gp_[0] > 0)), 0.0, gp_[0])
+        assert np.abs(pgp).max() < 1e-5 * max(1.0, np.abs(alpha).max())
 
 
 # ---- the next_query dispatcher against the reference's own outputs (tools/make_golden_r2.py) -----------------

@@ -15,15 +15,15 @@ for name in names:
     S = eng.gram(g["X"], th, str(g["kernel"]))
     Sinv, L = eng.pd_inverse_chol(S)
     f0 = eng.dev(g["f_init"])
-    for mode in ("whitened", "tr"):
+    for mode in ("whitened2", "whitened", "tr"):
         if mode == "tr" and name == "c5":
             continue
-        kw = dict(L=L) if mode == "whitened" else {}
+        kw = dict(L=L, Sigma=S) if mode == "whitened2" else (dict(L=L) if mode == "whitened" else {})
         eng.fit_fmap(Sinv, f0, m, th[0], gtol=gtol, **kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         f, st = eng.fit_fmap(Sinv, f0, m, th[0], gtol=gtol, verbose=verbose, **kw)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
         _, gr = eng.T_and_grad(Sinv, f, m, th[0])
-        print(f"{name:10s} {mode:8s} {dt:8.2f} ms  lbfgs it/ev/status {st['lbfgs_iterations']}/{st['lbfgs_evals']}/{st['lbfgs_status']}"
+        print(f"{name:10s} {mode:9s} {dt:8.2f} ms  lbfgs it/ev/status {st['lbfgs_iterations']}/{st['lbfgs_evals']}/{st['lbfgs_status']}"
               f"  TR it {st['iterations']} chol {st['n_cholesky']}  |grad_f| {float(torch.linalg.norm(gr)):.2e} (ref {float(g['gradnorm_fMAP']):.2e})"
               f"  T {st['T']:.12f} (ref {float(g['T_fMAP']):.12f})  max|f-fref| {np.abs(f.cpu().numpy() - g['fMAP']).max():.2e}", flush=True)
