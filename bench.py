@@ -288,7 +288,7 @@ def main():
             Sinv, Lc = eng.pd_inverse_chol(Sigma)
         else:
             Sinv, Lc = eng.pd_inverse(Sigma), None
-        fmap, st = eng.fit_fmap(Sinv, f_init, m, th[0], gtol=1e-4, L=Lc, Sigma=Sigma if whitened else None)
+        fmap, st = eng.fit_fmap(Sinv, f_init, m, th[0], gtol=1e-4, L=Lc)
         post = eng.posterior(Xd, th, kern, Sinv, fmap, m)
         return post, st
     post, st = fit_once()            # warm (allocates workspaces)

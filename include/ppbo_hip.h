@@ -171,15 +171,11 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
  * tens of O(N^3) factorizations.  It stops on the reference's own rule |grad_f T|_2 < gtol; whatever is left
  * (a request below the rounding floor of the whitened iteration, a stalled line search) is finished by
  * ppbo_fit_fmap from the point reached, so the result satisfies exactly what ppbo_fit_fmap's does.
- * d_Sigma (optional, may be NULL): Sigma itself.  With it an evaluation is TWO launches instead of five to six:
- * f = L z and v = Sigma^-1 f are linear in z and are carried along as images of the iteration's vectors, and the
- * only matrix products left, L^T beta and Sigma beta, share one kernel (a dependent launch costs ~8 us on
- * MI355X however small it is).
  * Same optimum as the reference on every golden fixture; the PATH (and hence, on a multi-modal posterior, which
  * local maximum is found) is not SciPy's. */
-int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma,
-                           const double* d_Sigma_inv, int N, int m, double sigma, const double* d_f_init,
-                           const ppbo_fit_opts* opts, double* d_fMAP, ppbo_fit_stats* h_stats, void* stream);
+int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m,
+                           double sigma, const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
+                           ppbo_fit_stats* h_stats, void* stream);
 
 /* T(f) and grad T(f) for a given f (src/gp_model.py:221-240); h_T / d_grad may be NULL */
 int ppbo_T_and_grad(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_f, int N, int m,

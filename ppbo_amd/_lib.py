@@ -60,7 +60,7 @@ SIGNATURES = {
     "ppbo_pd_inverse_append_ex": [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_laplace_terms": [_vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp],
     "ppbo_fit_fmap": [_vp, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
-    "ppbo_fit_fmap_whitened": [_vp, _vp, _i, _vp, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
+    "ppbo_fit_fmap_whitened": [_vp, _vp, _i, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
     "ppbo_T_and_grad": [_vp, _vp, _vp, _i, _i, _d, C.POINTER(_d), _vp, _vp],
     "ppbo_posterior": [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_predict": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _vp, _vp, _vp, C.POINTER(_d), C.POINTER(_i64), _vp],

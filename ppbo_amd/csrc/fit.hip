@@ -375,23 +375,11 @@ static_assert(sizeof(WhHead) == offsetof(WhState, B), "WhHead mirrors the head o
 //            the old matrix by algebra (s_new = alpha d is a combination of the old basis: s_new.b = alpha (B delta),
 //            y_new.b = g_t.b - g.b) -- "vector-free" L-BFGS; then the two-loop recursion on coefficients;
 //   pass 2   commit z, g and the pair, form the next direction and the next trial point.
-// Images of the iteration under L and L^-T (the two-launch slot, see below): f = L z and v = L^-T z = Sigma^-1 f are
-// LINEAR in z, so the trial point's f and v follow from those of the accepted point and of the basis vectors by
-// the same linear combination that forms the trial z -- no product with L or Sigma^-1 per evaluation:
-//   s = zt - z      ->  L s = ft - fz,             L^-T s = vt - vz
-//   g = zt - L^T b  ->  L g = ft - Sigma beta = ft - w,   L^-T g = vt - beta      (b = beta(ft), w from the fused launch)
-//   y = g - g_old   ->  differences of the above
-struct LbImages {
-  double *fz, *ft, *Fd, *FB;      // L z, L zt, L d, L b_l  [LB_NB][N]
-  double *vz, *vt, *Vd, *VB;      // the same under L^-T
-  const double* w;                // Sigma beta(ft)
-};
-
-template <int NT, bool IMG>
+template <int NT>
 __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int m, int n_q, double* __restrict__ z,
                                            double* __restrict__ zt, double* __restrict__ d, const double* u,
                                            const double* v, const double* beta, const double* tq,
-                                           double* __restrict__ basis, const LbImages& im) {
+                                           double* __restrict__ basis) {
   constexpr int HW = (int)(sizeof(WhHead) / 4);
   constexpr int NA = 7 + LB_NB + 1;      // zz, tsum, gf2, sy, ss, yy, gt.d | gt.b_l | gt.gt
   __shared__ double shB[LB_NB * LB_NB];
@@ -408,7 +396,7 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
   if (tid < LB_NB) delta[tid] = st->delta[tid];
   __syncthreads();
   if (hs.status != 0) return;
-  const int first = hs.first, need_gf = IMG ? 1 : hs.need_gf;     // with the images v = Sigma^-1 f costs nothing
+  const int first = hs.first, need_gf = hs.need_gf;
   double* gcur = basis + (size_t)(2 * LB_H) * N;
   const double c1 = 1e-4, c2 = 0.9, eps_f = 1e-13;
   // ---- pass 1
@@ -485,21 +473,10 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
   if (a != 1) {
     if (a == 0) {                     // shorter step along the same direction
       const double an = shs[0];
-      for (int i = tid; i < N; i += NT) {
-        zt[i] = z[i] + an * d[i];
-        if (IMG) { im.ft[i] = im.fz[i] + an * im.Fd[i]; im.vt[i] = im.vz[i] + an * im.Vd[i]; }
-      }
+      for (int i = tid; i < N; i += NT) zt[i] = z[i] + an * d[i];
     } else if (a == 2) {              // steepest descent from the accepted point
       const double an = shs[0];
-      for (int i = tid; i < N; i += NT) {
-        const double di = -gcur[i];
-        d[i] = di; zt[i] = z[i] + an * di;
-        if (IMG) {
-          const double fd = -im.FB[(size_t)(2 * LB_H) * N + i], vd = -im.VB[(size_t)(2 * LB_H) * N + i];
-          im.Fd[i] = fd; im.ft[i] = im.fz[i] + an * fd;
-          im.Vd[i] = vd; im.vt[i] = im.vz[i] + an * vd;
-        }
-      }
+      for (int i = tid; i < N; i += NT) { const double di = -gcur[i]; d[i] = di; zt[i] = z[i] + an * di; }
       if (tid < LB_NB) st->delta[tid] = (tid == 2 * LB_H) ? -1.0 : 0.0;
     }
     if (tid < HW) reinterpret_cast<int*>(st)[tid] = reinterpret_cast<const int*>(&hs)[tid];
@@ -625,34 +602,6 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
       d[i] = di;
       zt[i] = zi + an * di;
     }
-    if (IMG) {           // the same commit and the same combination under L and under L^-T
-      const double fti = im.ft[i], vti = im.vt[i];
-      const double fg = fti - im.w[i], vg = vti - beta[i];
-      double fb[LB_NB], vb[LB_NB];
-#pragma unroll
-      for (int l = 0; l < LB_NB; ++l) { fb[l] = im.FB[(size_t)l * N + i]; vb[l] = im.VB[(size_t)l * N + i]; }
-      if (pair_ok) {
-        const double fs = fti - im.fz[i], fy = fg - fb[2 * LB_H], vs = vti - im.vz[i], vy = vg - vb[2 * LB_H];
-        im.FB[(size_t)r * N + i] = fs; im.FB[(size_t)(LB_H + r) * N + i] = fy;
-        im.VB[(size_t)r * N + i] = vs; im.VB[(size_t)(LB_H + r) * N + i] = vy;
-#pragma unroll
-        for (int l = 0; l < 2 * LB_H; ++l) {
-          if (l == r) { fb[l] = fs; vb[l] = vs; }
-          else if (l == LB_H + r) { fb[l] = fy; vb[l] = vy; }
-        }
-      }
-      fb[2 * LB_H] = fg; vb[2 * LB_H] = vg;
-      im.FB[(size_t)(2 * LB_H) * N + i] = fg; im.VB[(size_t)(2 * LB_H) * N + i] = vg;
-      im.fz[i] = fti; im.vz[i] = vti;
-      if (!stop) {
-        double fd = 0.0, vd = 0.0;
-#pragma unroll
-        for (int l = 0; l < LB_NB; ++l) { fd += delta[l] * fb[l]; vd += delta[l] * vb[l]; }
-        im.Fd[i] = fd; im.Vd[i] = vd;
-        im.ft[i] = fti + an * fd;
-        im.vt[i] = vti + an * vd;
-      }
-    }
   }
 }
 
@@ -662,91 +611,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_step_kernel(WhState* __restrict__ 
                                                           const double* __restrict__ v,
                                                           const double* __restrict__ beta,
                                                           const double* __restrict__ tq, double* __restrict__ basis) {
-  lbfgs_step<LB_T, false>(st, N, m, n_q, z, zt, d, u, v, beta, tq, basis, LbImages{});
-}
-
-__global__ __launch_bounds__(LB_T) void lbfgs_step_img_kernel(WhState* __restrict__ st, int N, int m, int n_q,
-                                                              double* __restrict__ z, double* __restrict__ zt,
-                                                              double* __restrict__ d, const double* __restrict__ u,
-                                                              const double* __restrict__ beta,
-                                                              const double* __restrict__ tq,
-                                                              double* __restrict__ basis, LbImages im) {
-  lbfgs_step<LB_T, true>(st, N, m, n_q, z, zt, d, u, im.vt, beta, tq, basis, im);
-}
-
-// The fused launch of the two-launch slot: every workgroup rebuilds beta(ft) for itself in LDS (N exponentials --
-// cheaper than a launch), then each wavefront owns one row: u_i = (L^T beta)_i through the row-major copy U of L^T,
-// and w_i = (Sigma beta)_i.  Workgroup 0 publishes beta, the last one the per-query likelihood sums.
-__global__ __launch_bounds__(256) void beta_products_kernel(const WhState* __restrict__ st,
-                                                            const double* __restrict__ ft, int N, int mblk, int n_q,
-                                                            double sigma, const double* __restrict__ U,
-                                                            const double* __restrict__ Sigma,
-                                                            double* __restrict__ beta, double* __restrict__ tq,
-                                                            double* __restrict__ u, double* __restrict__ w) {
-  extern __shared__ __attribute__((aligned(16))) double blds[];     // f [N] | beta [N]
-  if (st->status != 0) return;
-  double* sf = blds;
-  double* sb = blds + N;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int m = mblk - 1;
-  const bool liker = blockIdx.x == gridDim.x - 1;
-  for (int i = threadIdx.x; i < N; i += 256) sf[i] = ft[i];
-  __syncthreads();
-  const double bsc = sigma * (double)m;
-  for (int q = wv; q < n_q; q += 4) {
-    const int i = q * mblk;
-    const double f0 = sf[i];
-    double sp2 = 0.0, sphi = 0.0;
-    for (int r = 1 + lane; r <= m; r += 64) {
-      const double delta = (sf[i + r] - f0) / sigma;
-      const double p2 = INV_SQRT_4PI * exp(-0.25 * (delta * delta));
-      if (liker) sphi += 0.5 * erfc(-0.5 * delta);
-      sp2 += p2;
-      sb[i + r] = -p2 / bsc;
-    }
-    sp2 = wave_sum(sp2);
-    if (liker) sphi = wave_sum(sphi);
-    if (lane == 0) { sb[i] = sp2 / bsc; if (liker) tq[q] = sphi; }
-  }
-  __syncthreads();
-  if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < N; i += 256) beta[i] = sb[i];
-  const int i = blockIdx.x * 4 + wv;
-  if (i >= N) return;
-  const double* ur = U + (size_t)i * N;
-  const double* sr = Sigma + (size_t)i * N;
-  double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
-  // rows are 16-byte aligned (N even is checked by the caller); the triangle of U starts at column i
-  const int k0 = i & ~1;
-  for (int k = 2 * lane; k < N; k += 128) {
-    const double2 b2 = *reinterpret_cast<const double2*>(sb + k);
-    const double2 s2 = *reinterpret_cast<const double2*>(sr + k);
-    c0 += s2.x * b2.x; c1 += s2.y * b2.y;
-    if (k >= k0) {
-      const double2 u2 = *reinterpret_cast<const double2*>(ur + k);
-      a0 += u2.x * b2.x;          // U is zero left of its diagonal
-      a1 += u2.y * b2.y;
-    }
-  }
-  const double su = wave_sum(a0 + a1), sw = wave_sum(c0 + c1);
-  if (lane == 0) { u[i] = su; w[i] = sw; }
-}
-
-// U = L^T (upper triangle written, the rest zero; row pitch N); 32 x 32 tiles through LDS
-__global__ __launch_bounds__(256) void transpose_lower_kernel(const double* __restrict__ L, int N, int ldl,
-                                                              double* __restrict__ U) {
-  __shared__ double t[32][33];
-  const int bi = blockIdx.y, bj = blockIdx.x;        // tile of L at rows bi*32.., cols bj*32..
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < 32; r += 8) {
-    const int i = bi * 32 + r, j = bj * 32 + tx;
-    t[r][tx] = (i < N && j < N && j <= i) ? L[(size_t)i * ldl + j] : 0.0;
-  }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int j = bj * 32 + r, i = bi * 32 + tx;     // U[j][i] = L[i][j]
-    if (i < N && j < N) U[(size_t)j * N + i] = t[tx][r];
-  }
+  lbfgs_step<LB_T>(st, N, m, n_q, z, zt, d, u, v, beta, tq, basis);
 }
 
 struct FitWork {
@@ -1102,9 +967,9 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
   return 0;
 }
 
-int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma,
-                           const double* d_Sigma_inv, int N, int m, double sigma, const double* d_f_init,
-                           const ppbo_fit_opts* opts, double* d_fMAP, ppbo_fit_stats* h_stats, void* stream) {
+int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m,
+                           double sigma, const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
+                           ppbo_fit_stats* h_stats, void* stream) {
   PPBO_ENTER(ctx);
   PPBO_REQUIRE(ctx, d_L && d_Sigma_inv && d_f_init && d_fMAP, "null pointer");
   PPBO_REQUIRE(ctx, N > 0 && ldl >= N && m >= 1 && sigma > 0, "sizes");
@@ -1136,40 +1001,7 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
   if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, v, zt, 1, 1, s)) return rc;
   PpboGate run; run.skip_if_nonzero = &st->status;
   PpboGate run_gf = run; run_gf.skip_if_zero = &st->need_gf;
-  // ---- two launches per evaluation when Sigma itself is at hand (see LbImages): the fused beta / L^T beta / Sigma beta
-  // kernel and the judgement; otherwise five to six (f = L zt, Laplace terms, L^T beta in two, gated Sigma^-1 f,
-  // judgement).  A dependent launch costs ~8 us on MI355X whatever it does, and these kernels do little.
-  const bool images = d_Sigma != nullptr && (N % 2) == 0 && N <= 8192;
-  LbImages im{};
-  double* U = nullptr;
-  double* wv = nullptr;
-  size_t blds = 0;
-  if (images) {
-    const size_t extra = (size_t)N * N + (size_t)(2 * LB_NB + 8) * N;
-    U = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LBFGS_IMG, extra * sizeof(double));
-    if (!U) return (int)hipErrorOutOfMemory;
-    double* p = U + (size_t)N * N;
-    im.FB = p; p += (size_t)LB_NB * N;
-    im.VB = p; p += (size_t)LB_NB * N;
-    im.fz = p; p += N; im.ft = p; p += N; im.Fd = p; p += N;
-    im.vz = p; p += N; im.vt = p; p += N; im.Vd = p; p += N;
-    wv = p; p += N;
-    im.w = wv;
-    PPBO_HIP_CHECK(ctx, hipMemsetAsync(im.FB, 0, (size_t)2 * LB_NB * N * sizeof(double), s));
-    const int nt32 = (N + 31) / 32;
-    transpose_lower_kernel<<<dim3(nt32, nt32), 256, 0, s>>>(d_L, N, ldl, U);
-    // the first trial point IS the start vector: ft = f_init, vt = Sigma^-1 f_init (= v above), zt = L^T vt (above)
-    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(im.ft, d_f_init, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
-    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(im.vt, v, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
-    blds = (size_t)2 * N * sizeof(double);
-    if (blds > 48 * 1024) ppbo_lds_limit(ctx, (const void*)beta_products_kernel, 144 * 1024);
-  }
   auto enqueue_slot = [&]() -> int {
-    if (images) {
-      beta_products_kernel<<<(N + 3) / 4, 256, blds, s>>>(st, im.ft, N, mblk, n_q, sigma, U, d_Sigma, beta, tq, u, wv);
-      lbfgs_step_img_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, beta, tq, basis, im);
-      return 0;
-    }
     if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, zt, ft, 0, 1, s, run)) return rc;                  // f = L zt
     laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(ft, N, mblk, n_q, sigma, tq, beta, nullptr, nullptr);
     if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, beta, u, 1, 1, s, run)) return rc;                 // u = L^T beta
@@ -1177,7 +1009,7 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
     lbfgs_step_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, v, beta, tq, basis);
     return 0;
   };
-  int batch = images ? 8 : 4;
+  int batch = 4;
   for (;;) {
     for (int k = 0; k < batch; ++k)
       if (int rc = enqueue_slot()) return rc;
@@ -1185,9 +1017,8 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
     PPBO_HIP_CHECK(ctx, hipMemcpyAsync(hst, st, head_bytes, hipMemcpyDeviceToHost, s));
     PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
     if (verbose)
-      printf("[ppbo_fit whitened%s] evals %d iters %d phi %.12e |grad_z| %.3e |grad_f| %.3e status %d\n",
-             images ? ", 2 launches / evaluation" : "", hst->evals, hst->iters, hst->phi, std::sqrt(hst->gz2),
-             hst->gf2 >= 0 ? std::sqrt(hst->gf2) : -1.0, hst->status);
+      printf("[ppbo_fit whitened] evals %d iters %d phi %.12e |grad_z| %.3e |grad_f| %.3e status %d\n", hst->evals,
+             hst->iters, hst->phi, std::sqrt(hst->gz2), hst->gf2 >= 0 ? std::sqrt(hst->gf2) : -1.0, hst->status);
     if (hst->status != 0) break;
     if (batch < 16) batch *= 2;
   }

@@ -296,11 +296,10 @@ class Engine:
         return T.value, grad
 
     def fit_fmap(self, Sigma_inv, f_init, m, sigma, gtol=1e-4, maxiter=0, verbose=False, initial_radius=0.0, L=None,
-                 lbfgs_max_evals=0, Sigma=None):
+                 lbfgs_max_evals=0):
         """f_MAP from one start vector.  L = None: trust-region Newton on f (ppbo_fit_fmap, the reference's
         algorithm class); L = Cholesky factor of Sigma: whitened L-BFGS finished by that trust region
-        (ppbo_fit_fmap_whitened) -- same optimum, tens of O(N^2) evaluations instead of O(N^3) factorizations.
-        Sigma (optional, with L): two launches per evaluation instead of five to six (see include/ppbo_hip.h)."""
+        (ppbo_fit_fmap_whitened) -- same optimum, tens of O(N^2) evaluations instead of O(N^3) factorizations."""
         f0 = self.dev(f_init).reshape(-1)
         N = f0.numel()
         out = self.empty(N)
@@ -311,9 +310,8 @@ class Engine:
                                         _ptr(out), C.byref(st), self._stream())
             self._check(rc, "ppbo_fit_fmap")
         else:
-            rc = self.lib.ppbo_fit_fmap_whitened(self.ctx, _ptr(L), L.stride(0), _ptr(Sigma), _ptr(Sigma_inv), N, m,
-                                                 float(sigma), _ptr(f0), C.byref(opts), _ptr(out), C.byref(st),
-                                                 self._stream())
+            rc = self.lib.ppbo_fit_fmap_whitened(self.ctx, _ptr(L), L.stride(0), _ptr(Sigma_inv), N, m, float(sigma),
+                                                 _ptr(f0), C.byref(opts), _ptr(out), C.byref(st), self._stream())
             self._check(rc, "ppbo_fit_fmap_whitened")
         stats = dict(iterations=st.iterations, n_cholesky=st.n_cholesky, converged=bool(st.converged), T=st.T,
                      gradnorm=st.gradnorm, lbfgs_iterations=st.lbfgs_iterations, lbfgs_evals=st.lbfgs_evals,

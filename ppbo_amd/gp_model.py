@@ -309,7 +309,7 @@ class GPModel:
             Sinv, L = eng.pd_inverse_chol(Sig)
         else:
             Sinv, L = eng.pd_inverse(Sig), None
-        fm, st = eng.fit_fmap(Sinv, f0, self.m, theta[0], gtol=1e-4, maxiter=500, L=L, Sigma=Sig)
+        fm, st = eng.fit_fmap(Sinv, f0, self.m, theta[0], gtol=1e-4, maxiter=500, L=L)
         _, _, ld, lo = eng.laplace_terms(fm, self.m, theta[0])
         sgn, logdet, _ = eng.laplace_logdet(Sig, ld, lo, self.m)
         log_evidence = st["T"] - 0.5 * sgn * logdet
@@ -441,8 +441,7 @@ class GPModel:
         # independent restarts (the reference's 10 on the last iteration, gp_model.py:96-97) run concurrently
         t_fit = time.time()
         L = self._dL if self.fMAP_method == "whitened" else None
-        jobs = [(lambda eng, f0=f0: eng.fit_fmap(self._dSigma_inv, f0, self.m, self.theta[0], gtol=gtol, L=L,
-                                                 Sigma=self._dSigma))
+        jobs = [(lambda eng, f0=f0: eng.fit_fmap(self._dSigma_inv, f0, self.m, self.theta[0], gtol=gtol, L=L))
                 for f0 in starts]
         results = self._run_concurrently(jobs, self._default_workers(self.N) if trials > 1 else 1)
         t_fit = (time.time() - t_fit) / max(trials, 1)
@@ -460,8 +459,7 @@ class GPModel:
                 # descent predicted / radius collapsed): the reference hands back SciPy's last iterate
                 # (gp_model.py:382-389); with the flag set, one fresh start from the prior is tried as well
                 print("---!!!--- f_MAP search stopped at |grad T| = " + str(st["gradnorm"]) + "; restarting from a prior draw")
-                fm2, st2 = self.eng.fit_fmap(self._dSigma_inv, self._draw_prior(), self.m, self.theta[0], gtol=gtol, L=L,
-                                             Sigma=self._dSigma)
+                fm2, st2 = self.eng.fit_fmap(self._dSigma_inv, self._draw_prior(), self.m, self.theta[0], gtol=gtol, L=L)
                 if st2["T"] > st["T"] or not np.isfinite(st["T"]):
                     fm, st = fm2, st2
             if self.verbose:

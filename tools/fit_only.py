@@ -18,7 +18,7 @@ for rep in range(4):
     else:
         Sinv, L = eng.pd_inverse(S), None
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    f, st = eng.fit_fmap(Sinv, f0, m, th[0], L=L, Sigma=S if whitened else None)
+    f, st = eng.fit_fmap(Sinv, f0, m, th[0], L=L)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     post = eng.posterior(X, th, kern, Sinv, f, m)
     torch.cuda.synchronize(); t3 = time.perf_counter()

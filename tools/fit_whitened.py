@@ -15,10 +15,10 @@ for name in names:
     S = eng.gram(g["X"], th, str(g["kernel"]))
     Sinv, L = eng.pd_inverse_chol(S)
     f0 = eng.dev(g["f_init"])
-    for mode in ("whitened2", "whitened", "tr"):
+    for mode in ("whitened", "tr"):
         if mode == "tr" and name == "c5":
             continue
-        kw = dict(L=L, Sigma=S) if mode == "whitened2" else (dict(L=L) if mode == "whitened" else {})
+        kw = dict(L=L) if mode == "whitened" else {}
         eng.fit_fmap(Sinv, f0, m, th[0], gtol=gtol, **kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         f, st = eng.fit_fmap(Sinv, f0, m, th[0], gtol=gtol, verbose=verbose, **kw)
