@@ -315,6 +315,18 @@ def main():
         _, tr_st = fit_once(whitened=False)
         torch.cuda.synchronize()
         tr_fit_ms = (time.perf_counter() - t0) * 1e3
+    # (e) the model state is REPLICATED by running the same deterministic fit on every rank (no broadcast): check it --
+    # an exact checksum (int64 view, wrapping sum) of alpha and G per rank, gathered; must be bitwise equal
+    replicated_equal = None
+    if world > 1:
+        chk = torch.stack([post.alpha.view(torch.int64).sum(), post.G.view(torch.int64).sum()]).to(coll_dev)
+        allchk = torch.empty(2 * world, dtype=torch.int64, device=coll_dev)
+        dist.all_gather_into_tensor(allchk, chk)
+        allchk = allchk.cpu().view(world, 2)
+        replicated_equal = bool((allchk == allchk[0:1]).all())
+        if not replicated_equal and rank == 0:
+            print(f"bench.py: replicated fits differ between ranks: {allchk.tolist()}", file=sys.stderr)
+
     def burst_ms(fn, reps=40):
         """Steady-state duration of one launch of a SHORT kernel (8-100 us).  100 launches are captured in a HIP graph
         (torch.cuda.CUDAGraph over the stream the C-ABI launches on) and the graph is replayed back to back for tens
@@ -362,35 +374,57 @@ def main():
             e1.synchronize()
             return e0.elapsed_time(e1) / reps
 
-    def gram_burst_ms(Xg, reps=40):
-        out = eng.empty(Xg.shape[0], Xg.shape[0])      # one output buffer: no allocator traffic between launches
-        return burst_ms(lambda: eng.gram(Xg, th, kern, out=out), reps)
+    INFINITY_CACHE_BYTES = 256 * 2 ** 20     # MI355X: outputs below this are absorbed by the Infinity Cache, not HBM
+
+    def gram_burst(Xg, reps=40):
+        """Steady-state Gram time at this N, twice, plus the chip's write-only floor measured the same way:
+        resident  -- every launch writes the SAME output buffer: up to N = 4096 (134 MB) that buffer lives in the 256 MB
+                     Infinity Cache, so the figure is a fabric / last-level-cache write rate, NOT an HBM rate;
+        streaming -- the launches rotate over enough output buffers that the replay's footprint exceeds 512 MB: every
+                     byte has to reach HBM; this is the number the 8 TB/s roofline applies to;
+        floor     -- ppbo_store_floor (write-only 32 x 128 tiles, 16-byte write-through stores) over the same rotating
+                     buffers: the ceiling of any Gram kernel at this N on this chip, measured in this run."""
+        Ng = Xg.shape[0]
+        nbytes = 8 * Ng * Ng
+        nbuf = max(1, -(-(2 * INFINITY_CACHE_BYTES) // nbytes))
+        bufs = [eng.empty(Ng, Ng) for _ in range(nbuf)]
+        state = {"k": 0}
+
+        def rot(fn):
+            def call():
+                state["k"] = (state["k"] + 1) % nbuf
+                fn(bufs[state["k"]])
+            return call
+        res = burst_ms(lambda: eng.gram(Xg, th, kern, out=bufs[0]), reps)
+        stream = res if nbuf == 1 else burst_ms(rot(lambda o: eng.gram(Xg, th, kern, out=o)), reps)
+        floor = burst_ms(rot(lambda o: eng.store_floor(o)), reps)
+        gb = 8.0 * Ng * Ng + 8.0 * Ng * D
+        rate = lambda ms: gb / (ms * 1e-3) / 1e9
+        return {"N": Ng, "bytes": gb, "output_buffers_rotated": nbuf,
+                "resident_ms": res, "resident_GBs": rate(res), "resident_frac_of_8TBs": rate(res) / PEAK_HBM_GBS,
+                "resident_is_hbm": nbytes > INFINITY_CACHE_BYTES,
+                "streaming_ms": stream, "streaming_GBs": rate(stream), "frac": rate(stream) / PEAK_HBM_GBS,
+                "write_only_floor_ms": floor, "write_only_floor_frac": (8.0 * Ng * Ng) / (floor * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "frac_of_floor": floor / stream}
 
     # ---- candidates resident in HBM ----------------------------------------------------
     Xc = eng.dev(np.random.default_rng(1 + rank).random((M, D)))
     mustar = float(np.max(g["mu"]))
 
     # ---- steady-state rates of the HBM-bound kernels (rank 0), each under its own load (see burst_ms) ---------
-    gram_ms, gram_n, gram_sizes, pj_burst_ms = 0.0, 1, {}, None
+    gram_c3, gram_sizes, pj_burst_ms = None, {}, None
     F_RFF = 4096
     if rank == 0:
-        gram_ms = gram_burst_ms(Xd)
+        gram_c3 = gram_burst(Xd)
     if rank == 0 and not args.no_secondary:
         W_rff = eng.dev(np.random.default_rng(3).standard_normal((F_RFF, D)) / th[1])
         b_rff = eng.dev(np.random.default_rng(4).uniform(0, 2 * np.pi, F_RFF))
         Phi_out = eng.empty(F_RFF, N)
         pj_burst_ms = burst_ms(lambda: eng.rff_project(Xd, W_rff, b_rff, th[2], out=Phi_out))
         del Phi_out
-        # write-only floor of the chip for an N x N fp64 matrix, measured by tools/store_floor.hip
-        # (profiles/r01_gram_store_floor_v1.txt): the best any Gram kernel can reach at that N
-        floor_frac = {"2048": 0.69, "4096": 0.85, "8192": 0.82}
         for Ng in (4096, 8192):   # SURVEY 7: the Gram roofline is only meaningful beyond the launch-latency regime
             Xg = eng.dev(np.random.default_rng(7).random((Ng, D)))
-            gms = gram_burst_ms(Xg, 20)
-            gb = 8.0 * Ng * Ng + 8.0 * Ng * D
-            gram_sizes[str(Ng)] = {"avg_ms": gms, "achieved_GBs": gb / (gms * 1e-3) / 1e9,
-                                   "frac": gb / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                   "write_only_floor_frac": floor_frac[str(Ng)]}
+            gram_sizes[str(Ng)] = gram_burst(Xg, 20)
             del Xg
     eng.profile(True)
 
@@ -481,8 +515,6 @@ def main():
         exec_flops = sum(2.0 * wrows * M_launch * min(N, -(-((b + 1) * wrows) // mblk) * mblk) for b in range(-(-N // wrows)))
         dense_equiv = algo_flops / (qf_avg_ms * 1e-3) / 1e12
         executed = exec_flops / (qf_avg_ms * 1e-3) / 1e12
-        gram_bytes = 8.0 * N * N + 8.0 * N * D
-        gram_avg_ms = gram_ms / max(gram_n, 1)
         line = {
             "metric": "acquisition evals/sec (posterior mean + variance + EI + argmax per candidate)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -495,6 +527,7 @@ def main():
                                       + (" [TEST MODE: ranks share one GPU, gloo]" if share_gpu else "")},
             "gp_fit_ms": gp_fit_ms, "gp_fit_ms_runs": fit_runs, "gp_fit_start": fit_start, "gp_fit_iterations": st["iterations"],
             "gp_fit_cholesky": st["n_cholesky"],
+            "replicated_fit_bitwise_equal": replicated_equal,
             "gp_fit_method": "whitened L-BFGS (z = L^-1 f) + trust-region finisher (ppbo_fit_fmap_whitened)",
             "gp_fit_lbfgs": {"iterations": st["lbfgs_iterations"], "evals": st["lbfgs_evals"], "status": st["lbfgs_status"]},
             "gp_fit_trust_region_only": None if tr_st is None else {
@@ -512,15 +545,13 @@ def main():
             "kernels": {
                 "kstar_kernel": {"avg_ms": ks_ms / max(ks_n, 1), "launches": ks_n},
                 "score_kernel": {"avg_ms": sc_ms / max(sc_n, 1), "launches": sc_n},
-                "gram_kernel": {"bound": "hbm", "avg_ms": gram_avg_ms, "bytes": gram_bytes,
-                                "achieved_GBs": gram_bytes / (gram_avg_ms * 1e-3) / 1e9 if gram_avg_ms else None,
-                                "peak_GBs": PEAK_HBM_GBS,
-                                "frac": gram_bytes / (gram_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if gram_avg_ms else None,
-                                "write_only_floor_frac": 0.69,
-                                "note": "steady state: HIP-graph replay of 100 launches, clocks settled under the kernel's own "
-                                        "load; the chip absorbs a write-only 2048 x 2048 fp64 matrix at 0.69 of 8 TB/s with "
-                                        "write-through stores (tools/store_floor.hip): at this N a third of the kernel is "
-                                        "launch ramp and drain"},
+                "gram_kernel": dict(gram_c3 or {}, bound="hbm", peak_GBs=PEAK_HBM_GBS,
+                                    avg_ms=(gram_c3 or {}).get("streaming_ms"),
+                                    note="steady state: HIP-graph replay of 100 launches, clocks settled under the kernel's "
+                                         "own load.  `frac` = streaming rate (outputs rotated over > 512 MB, every byte reaches "
+                                         "HBM) / 8 TB/s; `resident_*` = one output buffer, which at this N sits in the 256 MB "
+                                         "Infinity Cache (a fabric / L3 write rate, not an HBM rate); `write_only_floor_*` = "
+                                         "ppbo_store_floor measured in this run over the same rotating buffers"),
             },
             "secondary": secondary,
             "best": {"value": best[0], "index": best[1]},
@@ -528,15 +559,17 @@ def main():
         # `traffic` needs rocprofv3 --pmc passes and cannot be measured from inside this process: it stays null.
         # The last committed PMC capture is quoted beside it ONLY while the kernel sources are the ones it was
         # taken with (tools/pmc_quadform.sh records the csrc digest).
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_hot_kernels.json")
-        if os.path.exists(pmc):
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_hot_kernels.json")))
+        pmc = pmcs[-1] if pmcs else ""
+        if pmc and os.path.exists(pmc):
             try:
                 from ppbo_amd.build import _digest
                 doc = json.load(open(pmc))
                 d = doc["quadform"]["derived"]
                 line["roofline"]["traffic_from_profile"] = {
                     "bytes_per_launch": d["fabric_read_bytes(FETCH_SIZE KB x1024 x2 gfx950 correction)"] + d["write_bytes"],
-                    "source": "profiles/r02_pmc_hot_kernels.json (FETCH_SIZE x2 + WRITE_SIZE, C3 launch)",
+                    "source": f"profiles/{os.path.basename(pmc)} (FETCH_SIZE x2 + WRITE_SIZE, C3 launch)",
                     "csrc_digest": doc.get("csrc_digest"), "current": doc.get("csrc_digest") == _digest()}
             except Exception:
                 pass

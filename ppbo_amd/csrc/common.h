@@ -22,7 +22,7 @@ struct ppbo_ctx {
   int device = 0;
   std::string err;
   // named workspace slots
-  enum { WS_KSTAR = 0, WS_PART, WS_SCRATCH, WS_LINALG, WS_LINALG2, WS_VEC, WS_SMALL, WS_POTRF, WS_APPEND, WS_DIST, WS_LBFGS, WS_SEARCH, WS_SEARCH_SMALL, WS_COUNT };
+  enum { WS_KSTAR = 0, WS_PART, WS_SCRATCH, WS_LINALG, WS_LINALG2, WS_VEC, WS_SMALL, WS_POTRF, WS_APPEND, WS_DIST, WS_LBFGS, WS_SEARCH, WS_SEARCH_SMALL, WS_LBFGS_U, WS_COUNT };
   void* ws[WS_COUNT] = {};
   size_t ws_bytes[WS_COUNT] = {};
   void* pinned = nullptr;  // small pinned host staging buffer
@@ -141,6 +141,30 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+// The same sum without the LDS crossbar: __shfl_xor compiles to ds_bpermute_b32, and a workgroup of 16 wavefronts
+// that all reduce through it is bound by the CU's one LDS pipe (measured: 12 us for 25 sums x 16 waves).  DPP moves
+// are plain VALU instructions: xor 1, xor 2 (quad_perm), row_half_mirror, row_mirror give every lane its row-of-16
+// sum; the four row sums are combined through scalar registers (v_readlane).  Fixed order: bitwise reproducible.
+__device__ __forceinline__ double dpp_add(double v, const int ctrl_selector) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  switch (ctrl_selector) {
+    case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); break;
+    case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); break;
+    case 2: lo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); break;
+    default: lo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); break;
+  }
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum_dpp(double v) { return dpp_add(dpp_add(v, 0), 1); }
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v = dpp_add(dpp_add(dpp_add(dpp_add(v, 0), 1), 2), 3);
+  double r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    r[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * k),
+                            __builtin_amdgcn_readlane(__double2loint(v), 16 * k));
+  return (r[0] + r[1]) + (r[2] + r[3]);
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll

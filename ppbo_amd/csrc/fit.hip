@@ -336,27 +336,40 @@ __global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ 
   }
 }
 
+// K sums over the NT threads of the workgroup, each thread holding K partials.  Quad sums by DPP (VALU only), one
+// lane per quad parks them in LDS ([K][NT/4]), 32 workers per value add NT/128 consecutive partials, one thread per
+// value the 32 results.  The first version reduced every value with six shuffle steps per wavefront: 16 waves x 25
+// values x 6 ds_bpermute pairs through ONE LDS pipe took 12 of the judgement kernel's 21 us.
 template <int K, int NT>
-__device__ __forceinline__ void lb_block_sum(double (&v)[K], double* __restrict__ red, double* __restrict__ out) {
+__device__ __forceinline__ void lb_block_sum(double (&v)[K], double* __restrict__ red, double* __restrict__ red2,
+                                             double* __restrict__ out) {
+  constexpr int P = NT / 4, C = 32, PER = P / C;
+  static_assert(P % C == 0 && K * C <= NT, "block-sum geometry");
+  const int tid = threadIdx.x;
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
+  for (int k = 0; k < K; ++k) v[k] = quad_sum_dpp(v[k]);
+  if ((tid & 3) == 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) red[w * K + k] = v[k];
+    for (int k = 0; k < K; ++k) red[k * P + (tid >> 2)] = v[k];
   }
   __syncthreads();
-  if (threadIdx.x < K) {
+  if (tid < K * C) {
+    const int k = tid / C, c = tid % C;
     double t = 0.0;
-    for (int ww = 0; ww < NT / 64; ++ww) t += red[ww * K + threadIdx.x];
-    out[threadIdx.x] = t;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) t += red[k * P + c * PER + i];
+    red2[k * C + c] = t;
+  }
+  __syncthreads();
+  if (tid < K) {
+    double t = 0.0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) t += red2[tid * C + c];
+    out[tid] = t;
   }
   __syncthreads();
 }
 
-// One judgement of the trial point zt (its products u = L^T beta(L zt), v = Sigma^-1 L zt and the per-query
-// likelihood sums tq are already in memory).  See the block comment above; tests/probes/whitened_lbfgs_proto.py is
-// the NumPy statement of the same recurrence.
 // The scalar head of WhState (everything before B), as the step works on it in LDS: global memory is read once at
 // the start and written once at the end -- a thread that loads, computes, stores and loads again from global memory
 // pays ~1 us per dependent access, which made the first version of this function take 25-45 us.
@@ -379,11 +392,14 @@ template <int NT>
 __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int m, int n_q, double* __restrict__ z,
                                            double* __restrict__ zt, double* __restrict__ d, const double* u,
                                            const double* v, const double* beta, const double* tq,
-                                           double* __restrict__ basis) {
+                                           double* __restrict__ basis, long long* dbg = nullptr) {
+  // verbose >= 2: wall_clock64 stamps of the phases of evaluations 3..9 (tools/fit_whitened.py <cfg> <gtol> 2)
+#define LSTAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = wall_clock64(); } while (0)
   constexpr int HW = (int)(sizeof(WhHead) / 4);
   constexpr int NA = 7 + LB_NB + 1;      // zz, tsum, gf2, sy, ss, yy, gt.d | gt.b_l | gt.gt
   __shared__ double shB[LB_NB * LB_NB];
-  __shared__ double red[(NT / 64) * NA];
+  __shared__ double red[NA * (NT / 4)];
+  __shared__ double red2[NA * 32];
   __shared__ double out[NA];
   __shared__ double delta[LB_NB];        // coefficients of the direction that produced the trial point (old basis)
   __shared__ double bdel[LB_NB];         // B delta
@@ -396,6 +412,8 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
   if (tid < LB_NB) delta[tid] = st->delta[tid];
   __syncthreads();
   if (hs.status != 0) return;
+  if (dbg) dbg += 16 * (hs.evals < 15 ? hs.evals : 15);
+  LSTAMP(1);
   const int first = hs.first, need_gf = hs.need_gf;
   double* gcur = basis + (size_t)(2 * LB_H) * N;
   const double c1 = 1e-4, c2 = 0.9, eps_f = 1e-13;
@@ -416,7 +434,9 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
     acc[7 + LB_NB] += gt * gt;
   }
   for (int q = tid; q < n_q; q += NT) acc[1] += tq[q];
-  lb_block_sum<NA, NT>(acc, red, out);
+  LSTAMP(2);
+  lb_block_sum<NA, NT>(acc, red, red2, out);
+  LSTAMP(3);
   // ---- the judgement (thread 0)
   if (tid == 0) {
     const double phi_t = 0.5 * out[0] + out[1] / (double)m;
@@ -469,6 +489,7 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
     act[0] = a; act[1] = pair_ok; act[2] = hs.head;
   }
   __syncthreads();
+  LSTAMP(4);
   const int a = act[0];
   if (a != 1) {
     if (a == 0) {                     // shorter step along the same direction
@@ -514,6 +535,7 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
     shB[(2 * LB_H) * LB_NB + l] = rg;      shB[l * LB_NB + 2 * LB_H] = rg;
   }
   __syncthreads();
+  LSTAMP(5);
   // ---- stopping tests (thread 0) and the next direction: vector-free two-loop, lane l of wavefront 0 = coefficient l
   if (tid == 0) {
     int hist = hs.hist, head = hs.head;
@@ -530,6 +552,7 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
     act[3] = stop;
   }
   __syncthreads();
+  LSTAMP(6);
   if (!act[3] && tid < 64) {
     const int l = tid;                                    // all 64 lanes take part in the reductions, l >= LB_NB adds 0
     const int hist = hs.hist, head = hs.head;
@@ -541,7 +564,7 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
       al[k] = 0.0;
       if (k >= hist) continue;
       const int rr = (head - hist + k + 2 * LB_H) % LB_H;
-      double t = wave_sum(live ? dl * shB[l * LB_NB + rr] : 0.0);
+      double t = wave_sum_dpp(live ? dl * shB[l * LB_NB + rr] : 0.0);
       t /= shB[rr * LB_NB + LB_H + rr];
       al[k] = t;
       if (l == LB_H + rr) dl -= t;
@@ -554,11 +577,11 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
     for (int k = 0; k < LB_H; ++k) {                      // oldest to newest
       if (k >= hist) continue;
       const int rr = (head - hist + k + 2 * LB_H) % LB_H;
-      double t = wave_sum(live ? dl * shB[l * LB_NB + LB_H + rr] : 0.0);
+      double t = wave_sum_dpp(live ? dl * shB[l * LB_NB + LB_H + rr] : 0.0);
       t /= shB[rr * LB_NB + LB_H + rr];
       if (l == rr) dl += al[k] - t;
     }
-    double dphi = wave_sum(live ? dl * shB[l * LB_NB + 2 * LB_H] : 0.0);
+    double dphi = wave_sum_dpp(live ? dl * shB[l * LB_NB + 2 * LB_H] : 0.0);
     const double gz2 = shB[(2 * LB_H) * LB_NB + 2 * LB_H];
     if (!(dphi < 0.0)) {                                  // not a descent direction: drop the history
       dl = (l == 2 * LB_H) ? -1.0 : 0.0;
@@ -573,6 +596,7 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
     }
   }
   __syncthreads();
+  LSTAMP(7);
   for (int i = tid; i < LB_NB * LB_NB; i += NT) st->B[i] = shB[i];
   if (tid < LB_NB) st->delta[tid] = delta[tid];
   if (tid < HW) reinterpret_cast<int*>(st)[tid] = reinterpret_cast<const int*>(&hs)[tid];
@@ -603,6 +627,8 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
       zt[i] = zi + an * di;
     }
   }
+  LSTAMP(8);
+#undef LSTAMP
 }
 
 __global__ __launch_bounds__(LB_T) void lbfgs_step_kernel(WhState* __restrict__ st, int N, int m, int n_q,
@@ -610,8 +636,80 @@ __global__ __launch_bounds__(LB_T) void lbfgs_step_kernel(WhState* __restrict__ 
                                                           double* __restrict__ d, const double* __restrict__ u,
                                                           const double* __restrict__ v,
                                                           const double* __restrict__ beta,
-                                                          const double* __restrict__ tq, double* __restrict__ basis) {
-  lbfgs_step<LB_T>(st, N, m, n_q, z, zt, d, u, v, beta, tq, basis);
+                                                          const double* __restrict__ tq, double* __restrict__ basis,
+                                                          long long* dbg) {
+  lbfgs_step<LB_T>(st, N, m, n_q, z, zt, d, u, v, beta, tq, basis, dbg);
+}
+
+// beta(f) and u = L^T beta in ONE launch: every workgroup rebuilds beta for itself in LDS (N exponentials -- cheaper
+// than a dependent launch), then each wavefront owns one row of the row-major copy U of L^T (zero left of the
+// diagonal): u_i = sum_{k >= i} U[i][k] beta[k].  Workgroup 0 publishes beta (the judgement needs it for |grad_f|),
+// the last workgroup the per-query likelihood sums.  Replaces laplace_kernel + gemvT_partial + sum_slabs in a slot.
+__global__ __launch_bounds__(256) void beta_lt_kernel(const int* __restrict__ status, const double* __restrict__ ft,
+                                                      int N, int mblk, int n_q, double sigma,
+                                                      const double* __restrict__ U, double* __restrict__ beta,
+                                                      double* __restrict__ tq, double* __restrict__ u) {
+  extern __shared__ __attribute__((aligned(16))) double blds[];     // f [N] | beta [N]
+  if (*status != 0) return;
+  double* sf = blds;
+  double* sb = blds + N;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int m = mblk - 1;
+  const bool liker = blockIdx.x == gridDim.x - 1;
+  for (int i = threadIdx.x; i < N; i += 256) sf[i] = ft[i];
+  __syncthreads();
+  const double bsc = sigma * (double)m;
+  for (int q = wv; q < n_q; q += 4) {
+    const int i = q * mblk;
+    const double f0 = sf[i];
+    double sp2 = 0.0, sphi = 0.0;
+    for (int r = 1 + lane; r <= m; r += 64) {
+      const double delta = (sf[i + r] - f0) / sigma;
+      const double p2 = INV_SQRT_4PI * exp(-0.25 * (delta * delta));
+      if (liker) sphi += 0.5 * erfc(-0.5 * delta);
+      sp2 += p2;
+      sb[i + r] = -p2 / bsc;
+    }
+    sp2 = wave_sum_dpp(sp2);
+    if (liker) sphi = wave_sum_dpp(sphi);
+    if (lane == 0) { sb[i] = sp2 / bsc; if (liker) tq[q] = sphi; }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < N; i += 256) beta[i] = sb[i];
+  const int i = blockIdx.x * 4 + wv;
+  if (i >= N) return;
+  const double* ur = U + (size_t)i * N;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int k = (i & ~1) + 2 * lane;          // rows are 16-byte aligned (N even); entries left of the diagonal are zero
+  for (; k + 128 < N; k += 256) {
+    const double2 u0 = *reinterpret_cast<const double2*>(ur + k), b0 = *reinterpret_cast<const double2*>(sb + k);
+    const double2 u1 = *reinterpret_cast<const double2*>(ur + k + 128), b1 = *reinterpret_cast<const double2*>(sb + k + 128);
+    a0 += u0.x * b0.x; a1 += u0.y * b0.y; a2 += u1.x * b1.x; a3 += u1.y * b1.y;
+  }
+  for (; k < N; k += 128) {
+    const double2 u0 = *reinterpret_cast<const double2*>(ur + k), b0 = *reinterpret_cast<const double2*>(sb + k);
+    a0 += u0.x * b0.x; a1 += u0.y * b0.y;
+  }
+  const double su = wave_sum_dpp((a0 + a1) + (a2 + a3));
+  if (lane == 0) u[i] = su;
+}
+
+// U = L^T (upper triangle, zero below; row pitch N); 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_lower_kernel(const double* __restrict__ L, int N, int ldl,
+                                                              double* __restrict__ U) {
+  __shared__ double t[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;        // tile of L at rows bi*32.., cols bj*32..
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    t[r][tx] = (i < N && j < N && j <= i) ? L[(size_t)i * ldl + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int j = bj * 32 + r, i = bi * 32 + tx;     // U[j][i] = L[i][j]
+    if (i < N && j < N) U[(size_t)j * N + i] = t[tx][r];
+  }
 }
 
 struct FitWork {
@@ -1001,12 +1099,34 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
   if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, v, zt, 1, 1, s)) return rc;
   PpboGate run; run.skip_if_nonzero = &st->status;
   PpboGate run_gf = run; run_gf.skip_if_zero = &st->need_gf;
+  long long* dbg = nullptr;
+  if (verbose > 1) {
+    dbg = (long long*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH_SMALL, 16 * 16 * sizeof(long long) + 512);
+    if (dbg) (void)hipMemsetAsync(dbg, 0, 16 * 16 * sizeof(long long), s);
+  }
+  // beta and L^T beta in one launch through a row-major copy of L^T.  The transposition is paid once per fit and every
+  // workgroup recomputes beta: a gain while launches dominate (C2, N = 512: 2.28 -> 1.97 ms; C4, N = 1024: 3.87 -> 2.96),
+  // a loss once the matrix passes do (C3, N = 2048: 1.12 -> 1.19 ms; C5 warm, N = 4096: 0.44 -> 0.58)
+  const bool fused = (N % 2) == 0 && N <= 1536;
+  double* U = nullptr;
+  const size_t blds = (size_t)2 * N * sizeof(double);
+  if (fused) {
+    U = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LBFGS_U, (size_t)N * N * sizeof(double));
+    if (!U) return (int)hipErrorOutOfMemory;
+    const int nt32 = (N + 31) / 32;
+    transpose_lower_kernel<<<dim3(nt32, nt32), 256, 0, s>>>(d_L, N, ldl, U);
+    if (blds > 48 * 1024) ppbo_lds_limit(ctx, (const void*)beta_lt_kernel, 144 * 1024);
+  }
   auto enqueue_slot = [&]() -> int {
     if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, zt, ft, 0, 1, s, run)) return rc;                  // f = L zt
-    laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(ft, N, mblk, n_q, sigma, tq, beta, nullptr, nullptr);
-    if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, beta, u, 1, 1, s, run)) return rc;                 // u = L^T beta
+    if (fused) {
+      beta_lt_kernel<<<(N + 3) / 4, 256, blds, s>>>(&st->status, ft, N, mblk, n_q, sigma, U, beta, tq, u);
+    } else {
+      laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(ft, N, mblk, n_q, sigma, tq, beta, nullptr, nullptr);
+      if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, beta, u, 1, 1, s, run)) return rc;               // u = L^T beta
+    }
     if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, ft, v, 0, 0, s, run_gf)) return rc;          // v = Sigma^-1 f
-    lbfgs_step_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, v, beta, tq, basis);
+    lbfgs_step_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, v, beta, tq, basis, dbg);
     return 0;
   };
   int batch = 4;
@@ -1021,6 +1141,18 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
              hst->iters, hst->phi, std::sqrt(hst->gz2), hst->gf2 >= 0 ? std::sqrt(hst->gf2) : -1.0, hst->status);
     if (hst->status != 0) break;
     if (batch < 16) batch *= 2;
+  }
+  if (dbg) {
+    long long h[256];
+    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    for (int e = 3; e < 10; ++e) {
+      const long long* t = h + 16 * e;
+      if (!t[1]) continue;
+      if (!t[8]) continue;            // a backtracking slot ends before the later stamps
+      printf("  [judgement at evaluation %d] pass1 %.2f | block sum %.2f | judge %.2f | gram %.2f | stop %.2f | two-loop %.2f | pass2 %.2f us\n",
+             e, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01,
+             (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01);
+    }
   }
   const int lb_status = hst->status, lb_iters = hst->iters, lb_evals = hst->evals;
   if (lb_status == 4) {

@@ -46,6 +46,7 @@ def test_gpus_2_runs_two_nccl_ranks():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     assert line["config"]["M_total"] == 16384 and line["config"]["M_per_gpu"] == 8192
+    assert line["replicated_fit_bitwise_equal"] is True          # two different GPUs, the same bits
     assert 0 <= line["best"]["index"] < 16384
     # the same job on one rank must pick the same candidate? no: ranks draw their own candidates (seed 1 + rank);
     # what must hold is that the winning index lies in the shard that reported it
@@ -82,6 +83,9 @@ def test_two_ranks_sharing_one_gpu(scaling):
     assert 0 <= line["best"]["index"] < line["config"]["M_total"]
     assert abs(line["value"] - line["config"]["M_total"] * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
     assert "TEST MODE" in line["config"]["parallelism"]
+    # every rank fitted the same model from the same inputs: alpha and G agree bit for bit (the replicas-instead-of-
+    # broadcast assumption of DESIGN 6)
+    assert line["replicated_fit_bitwise_equal"] is True
 
 
 @pytest.mark.gpu

@@ -1,7 +1,7 @@
 """Collapse the rocprofv3 --pmc passes written by tools/pmc_quadform.sh into one JSON: per hot kernel the
 per-launch average of every counter (dispatches of the same kernel averaged; multi-instance counters summed per
 dispatch by rocprofv3 already), plus the derived figures DESIGN.md quotes.
-usage: python tools/pmc_summary.py gpurun_out/pmc > profiles/r02_pmc_hot_kernels.json"""
+usage: python tools/pmc_summary.py gpurun_out/pmc > profiles/r03_pmc_hot_kernels.json"""
 import csv, glob, json, os, sys, collections
 
 root = sys.argv[1]
