@@ -473,6 +473,10 @@ def main():
         eng.profile(True)
         t_rs = timed(lambda: eng.rff_score(Xc, W, b, th[2], om, want_score=False), 5)
         rs_ms, rs_n = eng.profile_read("rff_score")
+        # K9: S, S_grad, diag(S_hessian) of the weight-space posterior from a resident Phi (random_fourier_sampler.py:106-122)
+        Phi_res = eng.rff_project(Xd, W, b, th[2])
+        t_terms = timed(lambda: eng.rff_terms(Phi_res, om, m, th[0]), 10)
+        del Phi_res
         B, G, S = 512, 70, 150
         rngl = np.random.default_rng(6)
         al = np.linspace(0.005, 0.995, G)
@@ -492,6 +496,9 @@ def main():
                             "note": "avg_ms = steady state (HIP-graph replay of 100 launches); wall = one call incl. allocation "
                                     "and host launch latency"},
             "rff_score_evals_per_s": M / t_rs, "rff_score_kernel_ms": rs_ms / max(rs_n, 1),
+            "rff_terms_ms": {"F": F, "N": N, "wall_ms_per_call": t_terms * 1e3,
+                             "note": "S + S_grad + diag(S_hessian) in one call (reads Phi twice: 2 x 8 F N bytes); the reference: "
+                                     "0.02 + 0.11 + 1.0 s"},
             "line_acq": {"lines": B, "grid": G, "draws": S, "ms": t_line * 1e3, "lines_per_s": B / t_line},
         }
         try:

@@ -36,7 +36,7 @@ def user(xi, x, lo, hi):
     return float(al[np.argmin(hartmann6(al[:, None] * xi[None, :] + x[None, :]))])
 
 
-def run(queries=30, strategy="PCD", m=31, seed=0, verbose=False, incremental=False):
+def run(queries=30, strategy="PCD", m=31, seed=0, verbose=False, incremental=False, method="whitened"):
     from ppbo_amd.acquisition import next_query
     from ppbo_amd.gp_model import GPModel
     from ppbo_amd.ppbo_settings import PPBO_settings
@@ -61,6 +61,7 @@ def run(queries=30, strategy="PCD", m=31, seed=0, verbose=False, incremental=Fal
         results = np.vstack([results, np.concatenate([a * xi + x, xi, [a]])])
         if gp is None:
             gp = GPModel(st, incremental=incremental)
+            gp.fMAP_method = method
         gp.update_feedback_processing_object(results)
         gp.update_data()
         gp.update_model()
@@ -82,11 +83,12 @@ def run(queries=30, strategy="PCD", m=31, seed=0, verbose=False, incremental=Fal
         trials = gp.fit_log[n_log:]
         hist.append(dict(fx=fx, N=gp.N, update_model_s=t_q, fit_s=sum(t["seconds"] for t in trials),
                          iterations=sum(t["iterations"] for t in trials), n_cholesky=sum(t["n_cholesky"] for t in trials),
-                         trials=len(trials)))
+                         evals=sum(t.get("lbfgs_evals", 0) for t in trials), trials=len(trials)))
         if verbose:
             h = hist[-1]
-            print(f"query {i + 1:3d}  N={gp.N:5d}  f(x*)={fx:+.4f}  fit: {h['trials']} start(s), {h['iterations']:4d} TR iterations, "
-                  f"{h['n_cholesky']:5d} factorizations, {h['fit_s'] * 1e3:8.1f} ms   elapsed {time.time() - t0:6.1f}s")
+            print(f"query {i + 1:3d}  N={gp.N:5d}  f(x*)={fx:+.4f}  fit: {h['trials']} start(s), {h['evals']:4d} L-BFGS evaluations, "
+                  f"{h['iterations']:4d} TR iterations, {h['n_cholesky']:5d} factorizations, {h['fit_s'] * 1e3:8.1f} ms, "
+                  f"update_model {h['update_model_s'] * 1e3:7.1f} ms   elapsed {time.time() - t0:6.1f}s")
     return gp, hist
 
 
@@ -98,15 +100,21 @@ if __name__ == "__main__":
     ap.add_argument("--incremental", action="store_true", help="bordered Sigma^-1 update + warm-started f_MAP (f-4)")
     ap.add_argument("--compare", action="store_true", help="run cold and incremental back to back and summarise")
     args = ap.parse_args()
-    modes = [False, True] if args.compare else [args.incremental]
+    # (incremental, f_MAP method): the trust region alone is what rounds 1-2 ran
+    modes = ([(False, "trust-region"), (False, "whitened"), (True, "whitened")] if args.compare
+             else [(args.incremental, "whitened")])
     summary = {}
-    for inc in modes:
-        print(f"---- {'incremental' if inc else 'cold (reference semantics: prior draw per update)'} ----")
-        gp, hist = run(args.queries, args.strategy, args.m, verbose=True, incremental=inc)
+    for inc, method in modes:
+        tag = f"{'incremental' if inc else 'cold (reference semantics: prior draw per update)'}, f_MAP by {method}"
+        print(f"---- {tag} ----")
+        gp, hist = run(args.queries, args.strategy, args.m, verbose=True, incremental=inc, method=method)
         body = hist[:-1] if len(hist) > 1 else hist            # the last query runs the reference's 10 random restarts
-        summary[inc] = dict(best=min(h["fx"] for h in hist), fit_ms=1e3 * np.mean([h["fit_s"] for h in body]),
-                            chol=np.mean([h["n_cholesky"] for h in body]), iters=np.mean([h["iterations"] for h in body]))
-        print("best f(x*) reached:", summary[inc]["best"], "(global minimum -3.322)")
-    for inc, s in summary.items():
-        print(f"{'incremental' if inc else 'cold       '}: mean per query (last excluded) fit {s['fit_ms']:8.1f} ms, "
-              f"{s['iters']:6.1f} TR iterations, {s['chol']:6.1f} factorizations; best f(x*) {s['best']:+.4f}")
+        summary[tag] = dict(best=min(h["fx"] for h in hist), fit_ms=1e3 * np.mean([h["fit_s"] for h in body]),
+                            upd_ms=1e3 * np.mean([h["update_model_s"] for h in body]),
+                            chol=np.mean([h["n_cholesky"] for h in body]), iters=np.mean([h["iterations"] for h in body]),
+                            evals=np.mean([h["evals"] for h in body]))
+        print("best f(x*) reached:", summary[tag]["best"], "(global minimum -3.322)")
+    for tag, s in summary.items():
+        print(f"{tag}: mean per query (last excluded) fit {s['fit_ms']:8.2f} ms (update_model {s['upd_ms']:7.2f} ms), "
+              f"{s['evals']:6.1f} L-BFGS evaluations, {s['iters']:6.1f} TR iterations, {s['chol']:6.1f} factorizations; "
+              f"best f(x*) {s['best']:+.4f}")

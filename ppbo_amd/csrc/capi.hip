@@ -83,6 +83,7 @@ int ppbo_ctx_create(int device, ppbo_ctx** out) {
   c->potrf_gen = env_int("PPBO_POTRF_GEN", 3);
   c->rff_nt = env_int("PPBO_RFF_NT", 0);
   c->gram_variant = env_int("PPBO_GRAM_VARIANT", -1);
+  c->rff_score_mfma = env_int("PPBO_RFF_SCORE_MFMA", 1);
   *out = c;
   return 0;
 }

@@ -227,6 +227,93 @@ __global__ __launch_bounds__(RS_THREADS) void rff_score_kernel(const double* __r
   if (c0 + 1 < M) part[(size_t)blockIdx.y * M + c0 + 1] = a1;
 }
 
+
+// K8 on the matrix cores (default; PPBO_RFF_SCORE_MFMA=0 selects rff_score_kernel above): phases of a 16-feature x
+// 16-candidate tile from one MFMA chain (b_f = the accumulator's initial value), cosine and omega-weighted row sum on
+// the VALU.  Wavefront = CGV groups of 16 candidates whose B fragments stay in registers; 32 feature rows staged per
+// step in LDS and read as A fragments by all four wavefronts.  Output layout of v_mfma_f64_16x16x4: lane (lr, lk) holds
+// features lk + 4r of the tile for candidate lr, so the weighted feature sum is 4 FMAs per lane and two xor-shuffles
+// at the very end.  Measured at C3 (M = 65536, F = 4096, D = 20; tools/rff_score_time.py): VALU kernel 0.48 ms,
+// this one 0.38 ms with 4 groups per wave (0.40 with 2 groups at 4 waves / SIMD).  It is NOT the halving a free
+// matrix pipe would give: the fp64 MFMA chain (268 M phases x 20 MAC at 16 MAC / cycle / SIMD = 0.14 ms) and the
+// cosine (0.19 ms of VALU issue) add up rather than overlap -- fp64 MFMA and fp64 VALU share the CU's DP datapath.
+template <int DP, int CGV, int MINW>
+__global__ __launch_bounds__(256, MINW) void rff_score_mfma_kernel(const double* __restrict__ Xc, int M, int D,
+                                                                const double* __restrict__ W, int F,
+                                                                const double* __restrict__ b,
+                                                                const double* __restrict__ omega, RffPoly P,
+                                                                int f_per_split, double* __restrict__ part) {
+  constexpr int Q = DP / 4, LD = DP + 2, CG = CGV, RJ = 32;
+  __shared__ __attribute__((aligned(16))) double ws[RJ * LD];
+  __shared__ double s_b[RJ], s_om[RJ];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+  const int cw = blockIdx.x * (64 * CG) + wv * (16 * CG);
+  double xb[CG][Q], a[CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) {
+    const int c = cw + 16 * g + lr;
+#pragma unroll
+    for (int kk = 0; kk < Q; ++kk) {
+      const int d = kk * 4 + lk;
+      xb[g][kk] = (d < D && c < M) ? Xc[(size_t)c * D + d] : 0.0;
+    }
+    a[g] = 0.0;
+  }
+  const int f_beg = blockIdx.y * f_per_split;
+  int f_end = f_beg + f_per_split;
+  if (f_end > F) f_end = F;
+  for (int r0 = f_beg; r0 < f_end; r0 += RJ) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < RJ * DP; e += 256) {
+      const int r = e / DP, d = e - r * DP;
+      const int f = r0 + r;
+      ws[r * LD + d] = (f < f_end && d < D) ? W[(size_t)f * D + d] : 0.0;
+    }
+    if (threadIdx.x < RJ) {
+      const int f = r0 + threadIdx.x;
+      s_b[threadIdx.x] = (f < f_end) ? b[f] : 0.0;
+      s_om[threadIdx.x] = (f < f_end) ? omega[f] : 0.0;   // zero weight kills padded rows
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < RJ / 16; ++t) {
+      if (r0 + 16 * t >= f_end) break;
+      double af[Q], br[4], omr[4];
+#pragma unroll
+      for (int kk = 0; kk < Q; ++kk) af[kk] = ws[(16 * t + lr) * LD + kk * 4 + lk];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { br[r] = s_b[16 * t + lk + 4 * r]; omr[r] = s_om[16 * t + lk + 4 * r]; }
+#pragma unroll
+      for (int g = 0; g < CG; ++g) {
+        double4_t acc = double4_t{br[0], br[1], br[2], br[3]};
+#pragma unroll
+        for (int kk = 0; kk < Q; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], xb[g][kk], acc, 0, 0, 0);
+        double v[4];
+        bool big = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) big |= !(fabs(acc[r]) < RFF_COS_FAST_RANGE);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rff_cos_fast(acc[r], P);
+        if (__builtin_amdgcn_ballot_w64(big)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (!(fabs(acc[r]) < RFF_COS_FAST_RANGE)) v[r] = P.c[0] * rff_cos_slow(acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[g] = fma(omr[r], v[r], a[g]);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < CG; ++g) {
+    double t = a[g];
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    const int c = cw + 16 * g + lr;
+    if (lk == 0 && c < M) part[(size_t)blockIdx.y * M + c] = t;
+  }
+}
+
 // partial[split][n] = sum_{f in split} Phi[f][n] omega[f]
 __global__ __launch_bounds__(256) void phiT_omega_kernel(const double* __restrict__ Phi, int F, int N,
                                                          const double* __restrict__ omega, int f_per_split,
@@ -395,6 +482,21 @@ int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const do
     const double* xc = d_Xc + (size_t)c_beg * D;
     dim3 grid((Mc + RS_THREADS * 2 - 1) / (RS_THREADS * 2), n_split);
     PpboProfScope pf(ctx, ppbo_ctx::PF_RFF_SCORE, s);
+    if (ctx->rff_score_mfma) {
+      dim3 gm((Mc + 255) / 256, n_split);
+#define RM_LAUNCH(DP) \
+  rff_score_mfma_kernel<DP, 4, 2><<<gm, 256, 0, s>>>(xc, Mc, D, d_W, F, d_b, d_omega, make_rff_poly(scale), f_per_split, part)
+      if (D <= 4) RM_LAUNCH(4);
+      else if (D <= 8) RM_LAUNCH(8);
+      else if (D <= 12) RM_LAUNCH(12);
+      else if (D <= 16) RM_LAUNCH(16);
+      else if (D <= 20) RM_LAUNCH(20);
+      else if (D <= 24) RM_LAUNCH(24);
+      else if (D <= 32) RM_LAUNCH(32);
+      else if (D <= 48) RM_LAUNCH(48);
+      else RM_LAUNCH(64);
+#undef RM_LAUNCH
+    } else {
 #define RS_LAUNCH(DP) \
   rff_score_kernel<DP><<<grid, RS_THREADS, 0, s>>>(xc, Mc, D, d_W, F, d_b, d_omega, make_rff_poly(scale), f_per_split, part)
     if (D <= 4) RS_LAUNCH(4);
@@ -409,6 +511,7 @@ int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const do
     else if (D <= 48) RS_LAUNCH(48);
     else RS_LAUNCH(64);
 #undef RS_LAUNCH
+    }
     PPBO_LAUNCH_CHECK(ctx);
     const int sblocks = (Mc + 255) / 256;
     score_kernel<<<sblocks, 256, 0, s>>>(part, n_split, nullptr, nullptr, 0, Mc, 0.0, PPBO_SCORE_MEAN, 0.0,
