@@ -269,6 +269,15 @@ int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const do
 int ppbo_rff_terms(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, double sigma,
                    const double* d_omega, double* h_S, double* d_grad, double* d_hdiag, void* stream);
 
+/* the maximiser of ONE posterior sample phi(x)^T omega, device-resident: replaces Hsampler.return_xstar's 5-30
+ * L-BFGS-B starts on NumPy phi / Dphi (src/random_fourier_sampler.py:143-176).  Scores the M candidates
+ * (ppbo_rff_score), keeps the K best that are > sep apart and runs the whole projected Barzilai-Borwein ascent of
+ * each inside one kernel with the analytic gradient -a sum_f omega_f sin(w_f.x + b_f) w_f (:51-53).
+ * d_x[K,D] / d_val[K]: refined maxima (rows >= *h_found: value -inf). */
+int ppbo_rff_search(ppbo_ctx* ctx, const double* d_cand, int64_t M, int D, const double* d_W, int F,
+                    const double* d_b, double sigma_f, const double* d_omega, int K, double sep, int iters,
+                    double tol, double* d_x, double* d_val, int* h_found, void* stream);
+
 /* ---- generic fp64 MFMA GEMM (exposed for tests and host-side composition) ----
  * C[M,N] = alpha op(A) op(B) + beta C.  transA/transB: 0 = as stored, 1 = transposed. */
 int ppbo_dgemm(ppbo_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha,

@@ -186,13 +186,55 @@ __device__ __forceinline__ void eval_mean_grad(const double* __restrict__ X, int
   }
 }
 
+// the objective of an ascent: fills red[wave][0..DP) with the gradient's and red[wave][DP] with the value's partial sums
 template <int KID, int DP>
-__global__ __launch_bounds__(256) void mean_ascent_kernel(const double* __restrict__ X, int N, int D, KernParams p,
-                                                          const double* __restrict__ alpha,
-                                                          const double* __restrict__ starts,
-                                                          const int* __restrict__ count, int iters, double tol,
-                                                          double* __restrict__ x_out, double* __restrict__ mu_out,
-                                                          int* __restrict__ it_out) {
+struct MeanEval {
+  const double* X; int N, D; KernParams p; const double* alpha;
+  __device__ __forceinline__ void operator()(const double* sx, double (*red)[DP + 1]) const {
+    eval_mean_grad<KID, DP>(X, N, D, p, alpha, sx, red);
+  }
+};
+
+// one posterior sample of the utility in weight space (random_fourier_sampler.py:45-53,166):
+//   f(x) = a sum_f omega_f cos(w_f.x + b_f),   grad f = -a sum_f omega_f sin(w_f.x + b_f) w_f,   a = sqrt(2 sf^2 / F)
+template <int DP>
+struct RffEval {
+  const double* W; int F, D; const double* b; const double* omega; double amp;
+  __device__ __forceinline__ void operator()(const double* sx, double (*red)[DP + 1]) const {
+    double xc[DP], g[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) { xc[d] = sx[d]; g[d] = 0.0; }
+    double m = 0.0;
+    for (int f = threadIdx.x; f < F; f += 256) {
+      const double* __restrict__ wf = W + (size_t)f * D;
+      double wv[DP], ph = b[f];
+#pragma unroll
+      for (int d = 0; d < DP; ++d) { wv[d] = (d < D) ? wf[d] : 0.0; ph = fma(wv[d], xc[d], ph); }
+      double sn, cs;
+      sincos(ph, &sn, &cs);
+      const double om = amp * omega[f];
+      m = fma(om, cs, m);
+      const double c = -om * sn;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) g[d] = fma(c, wv[d], g[d]);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    m = wave_sum(m);
+#pragma unroll
+    for (int d = 0; d < DP; ++d) g[d] = wave_sum(g[d]);
+    if (lane == 0) {
+      red[wave][DP] = m;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) red[wave][d] = g[d];
+    }
+  }
+};
+
+template <int DP, class EVAL>
+__global__ __launch_bounds__(256) void bb_ascent_kernel(EVAL ev, int D, const double* __restrict__ starts,
+                                                        const int* __restrict__ count, int iters, double tol,
+                                                        double* __restrict__ x_out, double* __restrict__ mu_out,
+                                                        int* __restrict__ it_out) {
   static_assert(DP <= 64, "lane = coordinate");
   __shared__ double red[4][DP + 1];
   __shared__ double sx[DP];
@@ -212,7 +254,7 @@ __global__ __launch_bounds__(256) void mean_ascent_kernel(const double* __restri
   }
   if (tid == 0) done = 0;
   __syncthreads();
-  eval_mean_grad<KID, DP>(X, N, D, p, alpha, sx, red);
+  ev(sx, red);
   __syncthreads();
   if (w0) {
     const int dd = d < DP ? d : DP - 1;
@@ -234,7 +276,7 @@ __global__ __launch_bounds__(256) void mean_ascent_kernel(const double* __restri
     }
     __syncthreads();
     if (done) break;
-    eval_mean_grad<KID, DP>(X, N, D, p, alpha, sx, red);
+    ev(sx, red);
     __syncthreads();
     if (w0) {
       const int dd = d < DP ? d : DP - 1;
@@ -266,12 +308,29 @@ __global__ __launch_bounds__(256) void shift_points_kernel(const double* __restr
 template <int KID>
 void launch_mean_ascent(const ppbo_model* m, const KernParams& p, const double* starts, const int* count, int K,
                         int iters, double tol, double* x_out, double* mu_out, int* it_out, hipStream_t s) {
-  if (KID == PPBO_KERNEL_CAMPHOR || m->D <= 8)
-    mean_ascent_kernel<KID, 8><<<K, 256, 0, s>>>(m->d_X, m->N, m->D, p, m->d_alpha, starts, count, iters, tol, x_out, mu_out, it_out);
-  else if (m->D <= 24)
-    mean_ascent_kernel<KID, 24><<<K, 256, 0, s>>>(m->d_X, m->N, m->D, p, m->d_alpha, starts, count, iters, tol, x_out, mu_out, it_out);
-  else
-    mean_ascent_kernel<KID, 64><<<K, 256, 0, s>>>(m->d_X, m->N, m->D, p, m->d_alpha, starts, count, iters, tol, x_out, mu_out, it_out);
+#define MA_LAUNCH(DP)                                                                                                 \
+  do {                                                                                                                \
+    MeanEval<KID, DP> ev{m->d_X, m->N, m->D, p, m->d_alpha};                                                        \
+    bb_ascent_kernel<DP, MeanEval<KID, DP>><<<K, 256, 0, s>>>(ev, m->D, starts, count, iters, tol, x_out, mu_out, it_out); \
+  } while (0)
+  if (KID == PPBO_KERNEL_CAMPHOR || m->D <= 8) MA_LAUNCH(8);
+  else if (m->D <= 24) MA_LAUNCH(24);
+  else MA_LAUNCH(64);
+#undef MA_LAUNCH
+}
+
+void launch_rff_ascent(const double* W, int F, int D, const double* b, const double* omega, double amp,
+                       const double* starts, const int* count, int K, int iters, double tol, double* x_out,
+                       double* v_out, hipStream_t s) {
+#define RA_LAUNCH(DP)                                                                                          \
+  do {                                                                                                         \
+    RffEval<DP> ev{W, F, D, b, omega, amp};                                                                    \
+    bb_ascent_kernel<DP, RffEval<DP>><<<K, 256, 0, s>>>(ev, D, starts, count, iters, tol, x_out, v_out, nullptr); \
+  } while (0)
+  if (D <= 8) RA_LAUNCH(8);
+  else if (D <= 24) RA_LAUNCH(24);
+  else RA_LAUNCH(64);
+#undef RA_LAUNCH
 }
 
 template <int KID>
@@ -377,6 +436,38 @@ extern "C" int ppbo_mean_search(ppbo_ctx* ctx, const ppbo_model* m, const double
     case PPBO_KERNEL_RQ: launch_mean_ascent<PPBO_KERNEL_RQ>(m, p, starts, count, K, iters, tol, d_x, d_mu, nullptr, s); break;
     default: launch_mean_ascent<PPBO_KERNEL_CAMPHOR>(m, p, starts, count, K, iters, tol, d_x, d_mu, nullptr, s); break;
   }
+  PPBO_LAUNCH_CHECK(ctx);
+  if (h_found) {
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(h_found, count, sizeof(int), hipMemcpyDeviceToHost, s));
+    PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
+
+extern "C" int ppbo_rff_search(ppbo_ctx* ctx, const double* d_cand, int64_t M, int D, const double* d_W, int F,
+                               const double* d_b, double sigma_f, const double* d_omega, int K, double sep, int iters,
+                               double tol, double* d_x, double* d_val, int* h_found, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_cand && d_W && d_b && d_omega && d_x && d_val, "null pointer");
+  PPBO_REQUIRE(ctx, M > 0 && M < ((int64_t)1 << 31) && D > 0 && D <= 64 && F > 0, "sizes (D <= 64)");
+  PPBO_REQUIRE(ctx, K > 0 && K <= 1024 && sep >= 0 && iters >= 0 && tol >= 0, "K (<= 1024) / sep / iters / tol");
+  hipStream_t s = (hipStream_t)stream;
+  const int T_MAX = 4096;
+  const int G = (int)((M + T_MAX - 1) / T_MAX);
+  const int T = (int)((M + G - 1) / G);
+  const size_t nd = (size_t)M + T + (size_t)K * D;
+  double* sc = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH, nd * sizeof(double) + ((size_t)T + 16) * sizeof(int));
+  if (!sc) return (int)hipErrorOutOfMemory;
+  double* gval = sc + M;
+  double* starts = gval + T;
+  int* gidx = (int*)(starts + (size_t)K * D);
+  int* count = gidx + T;
+  if (int rc = ppbo_rff_score(ctx, d_cand, M, D, d_W, F, d_b, sigma_f, d_omega, sc, nullptr, nullptr, stream)) return rc;
+  group_max_kernel<<<(T + 255) / 256, 256, 0, s>>>(sc, M, G, T, gval, gidx);
+  select_starts_kernel<<<1, 1024, (size_t)T * sizeof(double), s>>>(gval, gidx, T, d_cand, D, K, sep * sep, starts, count);
+  launch_rff_ascent(d_W, F, D, d_b, d_omega, std::sqrt(2.0 * sigma_f * sigma_f / (double)F), starts, count, K, iters, tol,
+                    d_x, d_val, s);
   PPBO_LAUNCH_CHECK(ctx);
   if (h_found) {
     PPBO_HIP_CHECK(ctx, hipMemcpyAsync(h_found, count, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -442,6 +442,20 @@ class Engine:
         self._check(rc, "ppbo_rff_score")
         return sc, bv.value, bi.value
 
+    def rff_search(self, cand, W, b, sigma_f, omega, K=32, sep=0.05, iters=200, tol=1e-10):
+        """Device-resident maximiser of phi(x)^T omega over the rows of `cand` (ppbo_rff_search): refined maxima
+        x[found, D], values[found] as NumPy arrays."""
+        cand, W, b, omega = self.dev(cand), self.dev(W), self.dev(b).reshape(-1), self.dev(omega).reshape(-1)
+        M, D = cand.shape
+        F = W.shape[0]
+        xs, vals = self.empty(K, D), self.empty(K)
+        found = C.c_int(0)
+        rc = self.lib.ppbo_rff_search(self.ctx, _ptr(cand), M, D, _ptr(W), F, _ptr(b), float(sigma_f), _ptr(omega), int(K),
+                                      float(sep), int(iters), float(tol), _ptr(xs), _ptr(vals), C.byref(found), self._stream())
+        self._check(rc, "ppbo_rff_search")
+        n = found.value
+        return xs[:n].cpu().numpy(), vals[:n].cpu().numpy()
+
     def rff_terms(self, Phi, omega, m, sigma):
         Phi, omega = self.dev(Phi), self.dev(omega).reshape(-1)
         F, N = Phi.shape

@@ -5,19 +5,19 @@ and the candidate scoring evaluated by the HIP kernels (ppbo_rff_project / _term
 Differences in *cost*, not in results: the reference's weight-space Hessian is diagonal
 (:118-122) but is returned, inverted and sampled as a dense F x F matrix (:134-140, 207-213);
 here the diagonal is kept as a vector (the dense forms are still produced on request for
-attribute compatibility).  The L-BFGS-B multi-start of return_xstar (:143-176) is seeded by a
-batched on-device argmax over candidates.
+attribute compatibility).  The L-BFGS-B multi-start of return_xstar (:143-176) is one device
+enqueue: batched candidate scoring, start selection and the whole multi-start gradient ascent (ppbo_rff_search).
 """
 from __future__ import annotations
 
 import time
 
 import numpy as np
-import scipy.optimize
 
 from .engine import get_engine
 
 SCORE_CANDIDATES = 65536
+RFF_STARTS = 32            # refined starts per posterior sample (the reference: 5-30 L-BFGS-B runs)
 
 
 class Hsampler:
@@ -139,24 +139,29 @@ class Hsampler:
         return sc.cpu().numpy(), bv, bi
 
     def return_xstar(self, omega):
+        """argmax_x phi(x)^T omega (:143-176).  The reference runs 5-30 L-BFGS-B searches from perturbed local maxima
+        of the posterior mean on NumPy phi / Dphi; here ONE device enqueue (ppbo_rff_search) scores a rotated resident
+        uniform pool plus such perturbations, keeps the RFF_STARTS best that are > 0.05 apart and runs the whole
+        projected gradient ascent of each inside one kernel; the best refined point is returned."""
+        import torch
         start = time.time()
         D = self.D
-        cand = np.random.uniform(0, 1, (SCORE_CANDIDATES, D))
+        pool = self.__dict__.get("_pool")
+        if pool is None:
+            pool = self._pool = self.eng.dev(np.random.uniform(0, 1, (SCORE_CANDIDATES, D)))
+        M = pool.shape[0]
         loc = np.atleast_2d(self.GP_xstars_local)
         k = min(len(loc) * 64, SCORE_CANDIDATES // 4)
-        cand[:k] = np.clip(loc[np.random.randint(len(loc), size=k)] + 0.01 * np.random.uniform(0, 1, (k, D)), 0, 1)
-        _, _, bi = self.eng.rff_score(cand, self.W, self.b.ravel(), self.theta[2], omega, want_score=False)
-        best_x, best_f = None, -1e10
-        for x0 in (cand[bi], cand[np.random.randint(k)]):
-            res = scipy.optimize.minimize(lambda x: -float(self.phi(x) @ omega), x0=x0, method="L-BFGS-B",
-                                          bounds=((0, 1),) * D, jac=lambda x: -(self.Dphi(x).T @ omega),
-                                          options={"disp": False, "maxiter": 5000})
-            f = float(self.phi(res.x) @ omega)
-            if f > best_f and np.all((res.x >= 0) & (res.x <= 1)):
-                best_x, best_f = res.x, f
+        near = np.clip(loc[np.random.randint(len(loc), size=k)] + 0.01 * np.random.uniform(0, 1, (k, D)), 0, 1)
+        work = torch.empty((M + k, D), dtype=torch.float64, device=self.eng.device)
+        self.eng.shift_points(pool, np.random.uniform(0, 1, D), out=work[:M])
+        work[M:].copy_(self.eng.dev(near))
+        xs, vals = self.eng.rff_search(work, self.W, self.b.ravel(), self.theta[2], omega, K=RFF_STARTS)
         if self.verbose:
             print("Optimization of f_approx took " + str(time.time() - start) + " seconds.")
-        return best_x
+        if len(vals) == 0 or not np.isfinite(vals).any():
+            return None
+        return xs[int(np.nanargmax(vals))]
 
     def return_xstar_for_dim(self, omega, dim, x_ref):
         x_ref = np.array(x_ref, dtype=float)

@@ -35,3 +35,15 @@ def test_argmax_combine_first_occurrence(eng):
     rec = eng.dev(np.array([[float("nan"), 4.0], [2.0, -1.0]]))
     v, i = eng.argmax_combine(rec)
     assert i == -1 and v != v
+
+
+@pytest.mark.parametrize("N", [2, 130, 512, 1000])
+def test_store_floor_probe_writes_every_entry(eng, N):
+    """ppbo_store_floor (the write-only ceiling bench.py times beside ppbo_gram) covers the whole N x N matrix,
+    ragged tile edges included, and rejects an odd N."""
+    out = torch.full((N, N), float("nan"), dtype=torch.float64, device=eng.device)
+    eng.store_floor(out)
+    assert not bool(torch.isnan(out).any())
+    if N > 2:
+        with pytest.raises(RuntimeError):
+            eng.store_floor(torch.empty((N - 1, N - 1), dtype=torch.float64, device=eng.device))

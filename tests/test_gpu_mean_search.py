@@ -121,3 +121,24 @@ def test_mu_star_per_trial_time_at_c2(golden):
     print(f"mu_star at C2: {per_trial:.2f} ms per trial; mustar {mustar:.9f} (DE: {float(x['mustar']):.9f}), {len(local)} local maxima")
     assert mustar >= float(x["mustar"]) - 1e-6 * abs(float(x["mustar"]))
     assert per_trial <= 3.0
+
+
+@pytest.mark.parametrize("name", ["smoke", "c2", "c3"])
+def test_rff_search_climbs_the_sampled_utility(eng, golden, name):
+    """ppbo_rff_search (Hsampler.return_xstar's device path): the refined maxima of phi(x)^T omega are stationary
+    points inside the box, at least as high as the best raw candidate, and the value returned is the function's."""
+    g = golden(name)
+    W, b, om, sf = g["rff_W"], g["rff_b"].ravel(), g["rff_omega"], float(g["theta"][2])
+    D = W.shape[1]
+    rng = np.random.default_rng(4)
+    cand = rng.random((20000, D))
+    raw = orc.rff_score(cand[:4000], W, b, sf, om)
+    xs, vals = eng.rff_search(cand, W, b, sf, om, K=32, sep=0.05, iters=200, tol=1e-10)
+    assert 1 <= len(vals) <= 32 and np.all((xs >= 0) & (xs <= 1))
+    assert vals.max() >= raw.max() - 1e-12
+    assert np.abs(orc.rff_score(xs, W, b, sf, om) - vals).max() <= 1e-9 * np.abs(vals).max() + 1e-13
+    a = np.sqrt(2.0 * sf * sf / W.shape[0])
+    best = xs[int(np.argmax(vals))]
+    grad = -a * (om * np.sin(W @ best + b)) @ W
+    g0 = -a * (om * np.sin(W @ cand[0] + b)) @ W
+    assert np.abs(_proj(best, grad)).max() <= 1e-4 * np.abs(g0).max() + 1e-10
