@@ -96,3 +96,15 @@ def assert_same_across_ranks(values, what: str, device=None, group=None):
     if not bool((out == out[0:1]).all()):
         raise RuntimeError(f"{what} differ between ranks (rank {rank} sees {out.tolist()}): every rank must draw them "
                            "from an identically seeded NumPy stream, or receive them from rank 0")
+
+
+def broadcast_posterior(post, src: int = 0, group=None):
+    """SURVEY 2.1 C2 / 8(e), the alternative to replicated fits: the rank `src` has fitted the model, every other rank
+    holds a Posterior of the same shapes (e.g. from torch.empty_like) and receives alpha, Lambda_MAP (star form) and G
+    by ONE broadcast each (RCCL over xGMI: 8 N^2 bytes for G, 33.5 MB at N = 2048).  In place; returns post."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return post
+    for t in (post.alpha, post.lam_diag, post.lam_off, post.G):
+        if t is not None:
+            dist.broadcast(t, src=src, group=group)
+    return post

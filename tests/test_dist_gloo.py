@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ppbo_amd.dist import allgather_argmax, allgather_strided, combine_best, shard_bounds
+from ppbo_amd.dist import (allgather_argmax, allgather_strided, assert_same_across_ranks, broadcast_posterior, combine_best,
+                           shard_bounds)
 
 
 def _free_port():
@@ -104,3 +105,48 @@ def test_theta_slices_are_gathered_in_item_order(n_total):
 
 def test_strided_gather_single_process():
     assert allgather_strided([1.0, 2.0, 3.0], 3) == [1.0, 2.0, 3.0]
+
+
+def _worker_bcast(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ppbo_amd.engine import Posterior
+    N = 64
+    gen = torch.Generator().manual_seed(5)
+    ref = [torch.randn(N, dtype=torch.float64, generator=gen) for _ in range(3)] + [torch.randn(N, N, dtype=torch.float64, generator=gen)]
+    if rank == 0:
+        post = Posterior("SE_kernel", (0.1, 0.3, 0.5), 31, torch.zeros(N, 2, dtype=torch.float64), *[t.clone() for t in ref])
+    else:
+        post = Posterior("SE_kernel", (0.1, 0.3, 0.5), 31, torch.zeros(N, 2, dtype=torch.float64),
+                         *[torch.full_like(t, float("nan")) for t in ref])
+    broadcast_posterior(post, src=0)
+    same = all(torch.equal(a, b) for a, b in zip((post.alpha, post.lam_diag, post.lam_off, post.G), ref))
+    ok = True
+    try:
+        assert_same_across_ranks([1.0, 2.0], "equal values")             # must pass
+    except RuntimeError:
+        ok = False
+    raised = False
+    try:
+        assert_same_across_ranks([float(rank)], "rank-dependent values")  # must raise on every rank
+    except RuntimeError:
+        raised = True
+    q.put((rank, same, ok, raised))
+    dist.destroy_process_group()
+
+
+def test_model_broadcast_and_rank_consistency_check():
+    """(e): the model-broadcast alternative to replicated fits, and the checksum guard evidence_batch uses."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bcast, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, ok, raised in res:
+        assert same and ok and raised, (rank, same, ok, raised)
