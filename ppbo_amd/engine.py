@@ -370,22 +370,17 @@ class Engine:
 
     def mean_search(self, post: Posterior, cand, K=32, sep=0.05, iters=100, tol=1e-9):
         """Device-resident maximiser of the posterior mean over the rows of `cand` (ppbo_mean_search): returns the
-        refined maxima x[found, D], mu[found] as NumPy arrays (one read-back)."""
+        refined maxima x[found, D], mu[found] as NumPy arrays."""
         cand = self.dev(cand)
         M, D = cand.shape
         md = self._model(post, False)
-        out = self.empty(K, D + 1)                  # [:, :D] points, [:, D] values: one buffer, one copy back
-        x, mu = out[:, :D], out[:, D]
         xs, mus = self.empty(K, D), self.empty(K)
         found = C.c_int(0)
         rc = self.lib.ppbo_mean_search(self.ctx, C.byref(md), _ptr(cand), M, int(K), float(sep), int(iters), float(tol),
                                        _ptr(xs), _ptr(mus), C.byref(found), self._stream())
         self._check(rc, "ppbo_mean_search")
-        out[:, :D].copy_(xs)
-        out[:, D].copy_(mus)
-        h = out.cpu().numpy()
         n = found.value
-        return h[:n, :D].copy(), h[:n, D].copy()
+        return xs[:n].cpu().numpy(), mus[:n].cpu().numpy()
 
     def mean_ascent(self, post: Posterior, starts, iters=100, tol=1e-9):
         starts = self.dev(starts)
