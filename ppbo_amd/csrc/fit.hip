@@ -299,7 +299,7 @@ struct WhState {
   int status;      // 0 running, 1 converged (|grad_f| < gtol), 2 stagnated at the rounding floor, 3 line search
                    // failed along steepest descent, 4 non-finite objective at the start, 5 evaluation budget spent
   int evals, iters, hist, head, first, ls, stall, need_gf, max_evals;
-  double phi, dphi, alpha, gz2, gf2, gate, gtol2;
+  double phi, dphi, alpha, gz2, gf2, gate, gtol2, gzbest;
   double B[LB_NB * LB_NB];
   double delta[LB_NB];   // coefficients (over the basis) of the direction behind the current trial point
 };
@@ -333,6 +333,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ 
     st->phi = 0.0; st->dphi = 0.0; st->alpha = 0.0; st->gz2 = 0.0; st->gf2 = -1.0;
     st->gate = gtol * sqrt(t);          // |grad_f| < gtol needs |grad_z| < gtol |L|_F
     st->gtol2 = gtol * gtol;
+    st->gzbest = INFINITY;
   }
 }
 
@@ -375,7 +376,7 @@ __device__ __forceinline__ void lb_block_sum(double (&v)[K], double* __restrict_
 // pays ~1 us per dependent access, which made the first version of this function take 25-45 us.
 struct WhHead {
   int status, evals, iters, hist, head, first, ls, stall, need_gf, max_evals;
-  double phi, dphi, alpha, gz2, gf2, gate, gtol2;
+  double phi, dphi, alpha, gz2, gf2, gate, gtol2, gzbest;
 };
 static_assert(sizeof(WhHead) == offsetof(WhState, B), "WhHead mirrors the head of WhState");
 
@@ -477,7 +478,11 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
     } else if (a == 1) {
       if (!first) {
         pair_ok = out[3] > 1e-10 * sqrt(out[4] * out[5]);
-        hs.stall = (phi - phi_t <= 1e-14 * fmax(1.0, fabs(phi))) ? hs.stall + 1 : 0;
+        // stagnation = the objective has stopped moving AND the gradient has stopped shrinking: next to the optimum
+        // phi changes by |g|^2 ~ 1e-15 per step, far below its own rounding, while |g| still falls by factors
+        const double gtgt = out[7 + LB_NB];
+        if (gtgt < 0.25 * hs.gzbest) { hs.gzbest = gtgt; hs.stall = 0; }
+        else hs.stall = (phi - phi_t <= 1e-14 * fmax(1.0, fabs(phi))) ? hs.stall + 1 : 0;
         hs.iters += 1;
       }
       hs.phi = phi_t;

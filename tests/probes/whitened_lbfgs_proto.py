@@ -65,6 +65,7 @@ def fit(name, gtol=1e-4, max_evals=3000, verbose=False):
     first, need_gf = True, False
     phi = dphi = alpha = 0.0
     evals = iters = ls = stall = 0
+    gzbest = np.inf
     d = np.zeros(N)
     status = 0
     c1, c2, eps_f = 1e-4, 0.9, 1e-13
@@ -114,7 +115,11 @@ def fit(name, gtol=1e-4, max_evals=3000, verbose=False):
                 basis[2 * H] = g_t
                 B[2 * H, :] = basis @ g_t
                 B[:, 2 * H] = B[2 * H, :]
-            stall = stall + 1 if phi - phi_t <= 1e-14 * max(1.0, abs(phi)) else 0
+            gtgt = float(g_t @ g_t)
+            if gtgt < 0.25 * gzbest:            # the gradient still shrinks by factors: not stagnation
+                gzbest, stall = gtgt, 0
+            else:
+                stall = stall + 1 if phi - phi_t <= 1e-14 * max(1.0, abs(phi)) else 0
         else:
             basis[2 * H] = g_t
             B[2 * H, 2 * H] = g_t @ g_t
