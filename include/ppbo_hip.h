@@ -71,6 +71,13 @@ int ppbo_profile_read(ppbo_ctx* ctx, const char* name, double* h_total_ms, int* 
 int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D,
               const double h_theta[3], double shrink, double* d_Sigma, void* stream);
 
+/* a-3 as its own operator: regularize_covariance(X, reg_level, pos_diag=True, jitter) of src/misc.py:71-88 applied
+ * IN PLACE to any device matrix d_K[N, ldk] (gp_model.py:150 calls it on the raw Gramian; ppbo_gram fuses the same
+ * closed form): negative diagonal entries -> jitter when pos_diag != 0, then K <- (1 - reg_level) K + reg_level tr(K)/N I
+ * (sklearn.covariance.shrunk_covariance).  The SVD round trip of misc.py:79-80 is the identity and is not executed. */
+int ppbo_regularize_covariance(ppbo_ctx* ctx, double* d_K, int N, int ldk, double reg_level, int pos_diag,
+                               double jitter, void* stream);
+
 /* measurement probe, not part of the path: a write-only pass over d_S[N,N] (32 x 128 tiles, 16-byte write-through
  * stores, the fastest store shape tools/store_floor.hip found): the ceiling of ANY Gram kernel at that N on this
  * chip.  bench.py times it beside ppbo_gram (`write_only_floor_*`) instead of quoting constants. */
@@ -133,6 +140,13 @@ int ppbo_pd_inverse_append_ex(ppbo_ctx* ctx, const double* d_A, int N, const dou
 int ppbo_laplace_terms(ppbo_ctx* ctx, const double* d_f, int N, int m, double sigma,
                        double* d_Tlik, double* d_beta, double* d_lam_diag,
                        double* d_lam_off, void* stream);
+
+/* sum_Phi_vec(order_of_derivative, f, sigma) of src/gp_model.py:206-218 (sum_Phi :176-204 is one element of it):
+ * d_out[q] for the n_q = N/(m+1) queries, order 0 = sum_j Phi(Delta_qj/sqrt2) (closed form of the Gauss-Hermite
+ * integral at :192), 1 = sum_j var2_normal_pdf(Delta_qj), 2 = sum_j -Delta_qj/2 var2_normal_pdf(Delta_qj);
+ * any other order is an argument error (the reference prints and returns None). */
+int ppbo_sum_phi(ppbo_ctx* ctx, const double* d_f, int N, int m, double sigma, int order, double* d_out,
+                 void* stream);
 
 /* ---- a-8: f_MAP by trust-region Newton -----------------------------------
  * replaces GPModel.update_fMAP's scipy.optimize.minimize(method='trust-exact')

@@ -50,6 +50,7 @@ SIGNATURES = {
     "ppbo_profile_reset": [_vp],
     "ppbo_profile_read": [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(_i)],
     "ppbo_gram": [_vp, _i, _vp, _i, _i, _dp3, _d, _vp, _vp],
+    "ppbo_regularize_covariance": [_vp, _vp, _i, _i, _d, _i, _d, _vp],
     "ppbo_store_floor": [_vp, _vp, _i, _vp],
     "ppbo_cross_cov": [_vp, _i, _vp, _i, _vp, _i, _i, _dp3, _vp, _i, _vp],
     "ppbo_potrf": [_vp, _vp, _i, _i, C.POINTER(_i), _vp],
@@ -59,6 +60,7 @@ SIGNATURES = {
     "ppbo_pd_inverse_append": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_pd_inverse_append_ex": [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_laplace_terms": [_vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp],
+    "ppbo_sum_phi": [_vp, _vp, _i, _i, _d, _i, _vp, _vp],
     "ppbo_fit_fmap": [_vp, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
     "ppbo_fit_fmap_whitened": [_vp, _vp, _i, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
     "ppbo_T_and_grad": [_vp, _vp, _vp, _i, _i, _d, C.POINTER(_d), _vp, _vp],

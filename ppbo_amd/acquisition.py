@@ -132,6 +132,35 @@ def _search_joint(xi_dims, GP_model, PPBO_settings, which, fixed_x=None):
     return perturbate_zerocoordinates(xis[0], xi_dims), perturbate_zerocoordinates(xs[0], x_dims)
 
 
+def _split(xi_plus_x, xi_dims, x_dims, D):
+    v = np.asarray(xi_plus_x, dtype=float)
+    v = v[0] if v.ndim == 2 else v              # GPyOpt hands its objective a (1, D) array (src/acquisition.py:85)
+    xi, x = np.zeros(D), np.zeros(D)
+    xi[list(xi_dims)] = v[list(xi_dims)]
+    x[list(x_dims)] = v[list(x_dims)]
+    return xi, x
+
+
+def EI_to_maximize(xi_plus_x, xi_dims, x_dims, GP_model, mc_samples):
+    """The single-point objective the reference hands to its optimiser (src/acquisition.py:84-90); the searches
+    below score whole batches of such points in one launch instead of calling this in a loop."""
+    return EI(*_split(xi_plus_x, xi_dims, x_dims, GP_model.D), GP_model, mc_samples)
+
+
+def EI_fixed_x_to_maximize(xi, xstar, xi_dims, GP_model, mc_samples):
+    """src/acquisition.py:109-113: xi's free coordinates vary, the line passes through xstar."""
+    v = np.asarray(xi, dtype=float)
+    v = v[0] if v.ndim == 2 else v
+    xi_ = np.array(xstar, dtype=float)
+    xi_[list(xi_dims)] = v
+    return EI(xi_, xstar, GP_model, mc_samples)
+
+
+def varmax_to_maximize(xi_plus_x, xi_dims, x_dims, GP_model, mc_samples):
+    """src/acquisition.py:180-186."""
+    return varmax(*_split(xi_plus_x, xi_dims, x_dims, GP_model.D), GP_model, mc_samples)
+
+
 def maximize_EI(xi_dims, GP_model, PPBO_settings):
     return _search_joint(xi_dims, GP_model, PPBO_settings, "ei")
 

@@ -54,6 +54,29 @@ __global__ __launch_bounds__(256) void laplace_kernel(const double* __restrict__
   }
 }
 
+// sum_Phi_vec of gp_model.py:206-218 as its own operator: out[q] = sum_j Phi^(order)((f[q(m+1)+j] - f[q(m+1)]) / sigma)
+// in the reference's conventions (gp_model.py:176-204): order 0 = Phi(Delta/sqrt2) (closed form of the
+// Gauss-Hermite cross-correlation integral), 1 = var2_normal_pdf(Delta), 2 = -Delta/2 var2_normal_pdf(Delta).
+__global__ __launch_bounds__(256) void sum_phi_kernel(const double* __restrict__ f, int N, int mblk, int n_q, double sigma,
+                                                      int order, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n_q) return;
+  const int i = q * mblk;
+  const double f0 = f[i];
+  double acc = 0.0;
+  for (int r = 1 + lane; r < mblk && i + r < N; r += 64) {
+    const double delta = (f[i + r] - f0) / sigma;
+    if (order == 0) acc += 0.5 * erfc(-0.5 * delta);
+    else {
+      const double p2 = INV_SQRT_4PI * exp(-0.25 * (delta * delta));
+      acc += (order == 1) ? p2 : -0.5 * delta * p2;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[q] = acc;
+}
+
 // out[0] = -(1/m) sum_q tq[q]
 __global__ __launch_bounds__(1024) void tlik_reduce_kernel(const double* __restrict__ tq, int n_q, int m,
                                                            double* __restrict__ out) {
@@ -789,6 +812,17 @@ int ppbo_laplace_terms(ppbo_ctx* ctx, const double* d_f, int N, int m, double si
   }
   laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(d_f, N, mblk, n_q, sigma, tq, d_beta, d_lam_diag, d_lam_off);
   if (d_Tlik) tlik_reduce_kernel<<<1, 1024, 0, s>>>(tq, n_q, m, d_Tlik);
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int ppbo_sum_phi(ppbo_ctx* ctx, const double* d_f, int N, int m, double sigma, int order, double* d_out, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_f && d_out && N > 0 && m >= 1 && sigma > 0, "arguments");
+  PPBO_REQUIRE(ctx, N % (m + 1) == 0, "N must be n_q*(m+1) (feedback_processing.py:110-130)");
+  PPBO_REQUIRE(ctx, order >= 0 && order <= 2, "The derivatives of an order higher than 2 are not needed! (gp_model.py:203)");
+  const int n_q = N / (m + 1);
+  sum_phi_kernel<<<(n_q + 3) / 4, 256, 0, (hipStream_t)stream>>>(d_f, N, m + 1, n_q, sigma, order, d_out);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }

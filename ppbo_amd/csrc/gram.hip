@@ -328,6 +328,42 @@ __global__ __launch_bounds__(256) void store_floor_kernel(double* __restrict__ S
   }
 }
 
+
+// a-3 as a stand-alone operator (misc.py:71-88 applied to a matrix that did not come out of ppbo_gram):
+//   diagonal entries < 0 -> jitter; K <- (1 - s) K + s (tr K / n) I.  The SVD round trip of misc.py:79-80 is the
+// identity (oracle/ppbo_oracle.py regularize_covariance, tests/test_oracle_golden.py) and is not executed.
+// Pass 1 (one workgroup): clamp the diagonal in place and leave mu = tr(K)/n in mu_out.
+__global__ __launch_bounds__(1024) void regcov_trace_kernel(double* __restrict__ K, int N, int ldk, int pos_diag,
+                                                            double jitter, double* __restrict__ mu_out) {
+  __shared__ double sh[16];
+  double t = 0.0;
+  for (int i = threadIdx.x; i < N; i += 1024) {
+    double d = K[(size_t)i * ldk + i];
+    if (pos_diag && d < 0.0) { d = jitter; K[(size_t)i * ldk + i] = d; }
+    t += d;
+  }
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0;
+    for (int w = 0; w < 16; ++w) a += sh[w];
+    *mu_out = a / (double)N;
+  }
+}
+
+// Pass 2: one thread per pair of columns (16-byte accesses when the row is aligned), rows on blockIdx.y.
+__global__ __launch_bounds__(256) void regcov_shrink_kernel(double* __restrict__ K, int N, int ldk, double shrink,
+                                                            const double* __restrict__ mu) {
+  const int i = blockIdx.y;
+  const double add = shrink * (*mu), om = 1.0 - shrink;
+  double* row = K + (size_t)i * ldk;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < N; j += gridDim.x * 256) {
+    const double v = om * row[j];
+    row[j] = (j == i) ? v + add : v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -408,6 +444,21 @@ int ppbo_cross_cov(ppbo_ctx* ctx, int kernel_id, const double* d_X1, int n1, con
     case PPBO_KERNEL_RQ: crosscov_kernel<PPBO_KERNEL_RQ><<<grid, 256, lds, s>>>(d_X1, n1, d_X2, n2, D, p, d_K, ldk); break;
     default: crosscov_kernel<PPBO_KERNEL_CAMPHOR><<<grid, 256, lds, s>>>(d_X1, n1, d_X2, n2, D, p, d_K, ldk); break;
   }
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+int ppbo_regularize_covariance(ppbo_ctx* ctx, double* d_K, int N, int ldk, double reg_level, int pos_diag, double jitter,
+                               void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_K && N > 0 && ldk >= N, "matrix");
+  PPBO_REQUIRE(ctx, reg_level >= 0.0 && reg_level <= 1.0, "reg_level must be in [0, 1] (sklearn shrunk_covariance)");
+  hipStream_t s = (hipStream_t)stream;
+  double* mu = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, sizeof(double));
+  if (!mu) return (int)hipErrorOutOfMemory;
+  regcov_trace_kernel<<<1, 1024, 0, s>>>(d_K, N, ldk, pos_diag, jitter, mu);
+  const int bx = (N + 255) / 256 < 8 ? (N + 255) / 256 : 8;
+  regcov_shrink_kernel<<<dim3(bx, N), 256, 0, s>>>(d_K, N, ldk, reg_level, mu);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -285,6 +285,25 @@ class Engine:
         self._check(rc, "ppbo_laplace_terms")
         return float(T.item()), beta, ld, lo
 
+    def sum_phi(self, f, m, sigma, order):
+        """Per-query sums of src/gp_model.py:206-218 (device tensor [N / (m+1)])."""
+        f = self.dev(f).reshape(-1)
+        N = f.numel()
+        out = self.empty(N // (m + 1))
+        rc = self.lib.ppbo_sum_phi(self.ctx, _ptr(f), N, m, float(sigma), int(order), _ptr(out), self._stream())
+        self._check(rc, "ppbo_sum_phi")
+        return out
+
+    def regularize_covariance(self, K, reg_level=1e-4, pos_diag=True, jitter=1e-7):
+        """src/misc.py:71-88 on a device copy of K (the caller's matrix is left alone, as the reference's callers
+        use the returned value)."""
+        K = self.dev(K).clone()
+        N = K.shape[0]
+        rc = self.lib.ppbo_regularize_covariance(self.ctx, _ptr(K), N, K.stride(0), float(reg_level), int(bool(pos_diag)),
+                                                 float(jitter), self._stream())
+        self._check(rc, "ppbo_regularize_covariance")
+        return K
+
     def T_and_grad(self, Sigma_inv, f, m, sigma):
         f = self.dev(f).reshape(-1)
         N = f.numel()

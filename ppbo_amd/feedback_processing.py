@@ -42,20 +42,28 @@ class FeedbackProcessing:
     # ---- data flow -------------------------------------------------------------
     def initialize_data(self, X_obs):
         self.X_obs = np.asarray(X_obs, dtype=float)
+        self.create_X()
+        self.create_indices_bookkeeping()
+
+    def update_data(self, X_obs):
+        self.iter_number += 1
+        self.X_obs = np.asarray(X_obs, dtype=float)
+        self.update_X()
+        self.create_indices_bookkeeping()
+
+    def create_X(self):
+        """X_full / X / N from every row of X_obs (src/feedback_processing.py:110-130)."""
         self.X_full = np.vstack([self._query_block(r) for r in self.X_obs])
         self._finish()
 
-    def update_data(self, X_obs):
-        """One more query row appended to X_obs (src/feedback_processing.py:133-154)."""
-        self.iter_number += 1
-        self.X_obs = np.asarray(X_obs, dtype=float)
+    def update_X(self):
+        """X_obs has ONE more row than X_full covers: append its block (src/feedback_processing.py:133-154)."""
         self.X_full = np.vstack([self.X_full, self._query_block(self.X_obs[-1])])
         self._finish()
 
     def _finish(self):
         self.X = self.scale(self.X_full[:, :self.D])
         self.N = self.X.shape[0]
-        self.create_indices_bookkeeping()
 
     def _query_block(self, row):
         D, m = self.D, self.m

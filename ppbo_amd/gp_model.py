@@ -232,19 +232,19 @@ class GPModel:
         return -Sinv + self.create_Lambda(f, theta[0])
 
     def sum_Phi_vec(self, order_of_derivative, f, sigma, over_all_indices=False):
-        """Per-query sums of gp_model.py:206-218 recovered from the device Laplace terms."""
-        f = np.asarray(f, dtype=float).ravel()
-        mb = self.m + 1
-        delta = (f.reshape(-1, mb)[:, 1:] - f.reshape(-1, mb)[:, :1]) / sigma
-        _, beta, ld, _ = self.eng.laplace_terms(f, self.m, sigma)
-        if order_of_derivative == 1:
-            out = beta.cpu().numpy()[::mb] * (sigma * self.m)
-        elif order_of_derivative == 2:
-            out = -ld.cpu().numpy()[::mb] * (self.m * sigma ** 2)
-        else:
-            from scipy.special import ndtr
-            out = ndtr(delta / np.sqrt(2.0)).sum(axis=1)
-        return np.repeat(out, mb) if over_all_indices else out
+        """gp_model.py:206-218 on the device (ppbo_sum_phi): one value per query, repeated over the query's m+1 rows
+        when over_all_indices.  Order 0 is the closed form Phi(Delta/sqrt2) of the Gauss-Hermite integral at :192."""
+        if order_of_derivative not in (0, 1, 2):
+            print("The derivatives of an order higher than 2 are not needed!")
+            return None
+        out = self.eng.sum_phi(np.asarray(f, dtype=float).ravel(), self.m, sigma, order_of_derivative).cpu().numpy()
+        return np.repeat(out, self.m + 1) if over_all_indices else out
+
+    def sum_Phi(self, i, order_of_derivative, f, sigma, sample_points=None, weights=None):
+        """gp_model.py:176-204: the sum for the query whose observation row is i (an element of obs_indices).  The
+        quadrature arguments are accepted and unused (closed form)."""
+        v = self.sum_Phi_vec(order_of_derivative, f, sigma)
+        return None if v is None else float(v[int(i) // (self.m + 1)])
 
     # ------------------------------------------------------------------ concurrent fits (SURVEY 8f f-3)
     def _side_engines(self, n):

@@ -1,5 +1,8 @@
-"""Host-side helpers of the drop-in (O(D) work, no GPU): interval of a projective line inside the
-box (src/misc.py:27-61) and the box corners used for initial queries (src/misc.py:143-147)."""
+"""src/misc.py for the drop-in.  Host-side helpers (O(D) work, no GPU): interval of a projective line inside the
+box (src/misc.py:27-61), the box corners used for initial queries (src/misc.py:143-147), the two normal densities.
+The matrix helpers the GP path calls -- regularize_covariance (src/misc.py:71-88), pd_inverse (:96-100),
+is_positive_definite (:120-126) -- keep the reference's names and NumPy-in / NumPy-out signatures and run on the
+device through the C-ABI (there is no host implementation behind them)."""
 from __future__ import annotations
 
 import itertools
@@ -34,3 +37,29 @@ def var2_normal_pdf(x):
 
 def std_normal_pdf(x):
     return np.exp(-0.5 * np.square(x)) / np.sqrt(2.0 * np.pi)
+
+
+def regularize_covariance(X, reg_level=1e-4, pos_diag=True, jitter=1e-7):
+    """src/misc.py:71-88 on the device (ppbo_regularize_covariance): negative diagonal -> jitter when pos_diag,
+    shrink toward tr(X)/n I; the SVD round trip is the identity and is not executed."""
+    from .engine import get_engine
+    return get_engine().regularize_covariance(np.asarray(X, dtype=float), reg_level, pos_diag, jitter).cpu().numpy()
+
+
+def pd_inverse(matrix):
+    """Inverse of a positive definite matrix (src/misc.py:96-100) by the device Cholesky + triangular inverse;
+    raises ppbo_amd.engine.NotPositiveDefinite where SciPy raises LinAlgError."""
+    from .engine import get_engine
+    return get_engine().pd_inverse(np.asarray(matrix, dtype=float)).cpu().numpy()
+
+
+def is_positive_definite(M):
+    """src/misc.py:120-126: does the (device) Cholesky factorization succeed?"""
+    from .engine import NotPositiveDefinite, get_engine
+    eng = get_engine()
+    try:
+        eng.potrf_(eng.dev(np.asarray(M, dtype=float)).clone())
+        return True
+    except NotPositiveDefinite:
+        print('Function is_positive_definite: Matrix is not positive definite!')
+        return False

@@ -25,10 +25,10 @@ def load_golden(name):
 def golden_names(pred=lambda n: True):
     if not os.path.isdir(GOLDEN):
         return []
-    # model fixtures only: `<cfg>_x.npz` (round-2 extras on <cfg>'s model state) and `g7.npz` (the C1 trace)
-    # are loaded by name where they are used
+    # model fixtures only: `<cfg>_x.npz` (round-2 extras on <cfg>'s model state), `compat_<cfg>.npz` (round-3 small
+    # operators) and `g7.npz` (the C1 trace) are loaded by name where they are used
     return sorted(f[:-4] for f in os.listdir(GOLDEN)
-                  if f.endswith(".npz") and not f.startswith("_") and not f.endswith("_x.npz") and f not in ("g7.npz", "tgn.npz")
+                  if f.endswith(".npz") and not f.startswith(("_", "compat_")) and not f.endswith("_x.npz") and f not in ("g7.npz", "tgn.npz")
                   and pred(f[:-4]))
 
 

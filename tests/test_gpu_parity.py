@@ -644,6 +644,9 @@ def test_every_dimension_bucket(eng, D, kernel):
     out = eng.predict(post, Xc)
     assert rel(host(out["mu"]), mu0) < 1e-7
     assert np.abs(host(out["var"]) - var0).max() <= 1e-7 * th[2] ** 2
+    o32 = eng.predict(post, Xc, want_best=False, kstar_fp32=True)      # the fp32-K* report path: buckets 6 / 20 / 64
+    assert np.abs(host(o32["mu"]) - mu0).max() <= 1e-3 * np.abs(mu0).max()
+    assert np.abs(host(o32["var"]) - var0).max() <= 1e-2 * th[2] ** 2
     mu_g, grad = eng.mean_grad(post, Xc[:17])
     mu1, g1 = orc.mean_grad(Xc[:17], X, th, Sinv0 @ f0, kernel)
     assert rel(host(mu_g), mu1) < 1e-7

@@ -218,3 +218,37 @@ def test_run_ppbo_loop_call_order_matches_the_reference(monkeypatch):
     log.clear()
     res2, *_ = nm.run_ppbo_loop(lambda xi, x: 0.5, xi0, x0.copy(), 0, st, adaptive_initialization=True)
     assert np.allclose(res2[1], [0.5, 0.5, 0.3, 0, 1, 0, 0.5])       # x := previous chosen point (0.5, 0.2, 0.3), then its 2nd coord zeroed
+
+
+def test_create_X_and_update_X_agree():
+    """src/feedback_processing.py:110-154: update_X appends the block of the newest row of X_obs to what create_X built
+    from the earlier rows; both routes draw one jittered grid per row in row order, so from the same NumPy seed they
+    give the same design."""
+    from ppbo_amd.feedback_processing import FeedbackProcessing
+    D, m = 3, 6
+    bounds = ((-1.0, 2.0), (0.0, 1.0), (-3.0, 3.0))
+    rng = np.random.default_rng(5)
+    rows = []
+    for q in range(5):
+        xi = np.zeros(D); xi[q % D] = 1.0
+        x = np.array([rng.uniform(lo, hi) for lo, hi in bounds]); x[q % D] = 0.0
+        a = rng.uniform(*bounds[q % D])
+        rows.append(list(a * xi + x) + list(xi) + [a])
+    X_obs = np.array(rows)
+    one = FeedbackProcessing(D, m, bounds, "equispaced", None)
+    np.random.seed(8)
+    one.initialize_data(X_obs)
+    two = FeedbackProcessing(D, m, bounds, "equispaced", None)
+    np.random.seed(8)
+    two.initialize_data(X_obs[:3])
+    for k in (4, 5):
+        two.update_data(X_obs[:k])
+    assert two.iter_number == one.iter_number + 2
+    assert np.array_equal(one.X_full, two.X_full) and np.array_equal(one.X, two.X) and one.N == two.N == 5 * (m + 1)
+    assert list(one.obs_indices) == list(two.obs_indices) == [q * (m + 1) for q in range(5)]
+    three = FeedbackProcessing(D, m, bounds, "equispaced", None)
+    three.X_obs = X_obs
+    np.random.seed(8)
+    three.create_X()                                    # the reference's two-step form (:37-38)
+    three.create_indices_bookkeeping()
+    assert np.array_equal(three.X, one.X)
