@@ -46,8 +46,10 @@ class GPModel:
         self.n_appends = 0           # bordered updates of Sigma^-1 actually performed (ppbo_pd_inverse_append)
         self.n_full_inversions = 0   # full potrf + trtri + GEMM inversions
         self.fMAP_restart_on_stall = False   # opt-in: refit from a fresh prior draw when the trust region stalls
-        # "whitened": L-BFGS in z = L^-1 f finished by the trust region (ppbo_fit_fmap_whitened; same optimum as the
-        # reference's trust-exact, O(N^2) per iteration); "trust-region": the exact Newton trust region on f alone
+        # "whitened": L-BFGS in z = L^-1 f finished by the trust region (ppbo_fit_fmap_whitened; O(N^2) per iteration; the
+        # reference's optimum wherever T has one -- at sigma << sigma_f T has several local maxima and every local method,
+        # SciPy's included, picks its own: DESIGN 5); anything else: the exact Newton trust region on f alone, which
+        # follows SciPy trust-exact's iteration rules
         self.fMAP_method = "whitened"
         self.fit_log = []            # one dict per update_fMAP trial: iterations, n_cholesky, warm, seconds
         s = PPBO_settings
