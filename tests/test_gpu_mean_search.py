@@ -142,3 +142,43 @@ def test_rff_search_climbs_the_sampled_utility(eng, golden, name):
     grad = -a * (om * np.sin(W @ best + b)) @ W
     g0 = -a * (om * np.sin(W @ cand[0] + b)) @ W
     assert np.abs(_proj(best, grad)).max() <= 1e-4 * np.abs(g0).max() + 1e-10
+
+
+@pytest.mark.parametrize("D", [1, 3, 7, 11, 16, 23, 33, 48, 64])
+@pytest.mark.parametrize("kernel", ["SE_kernel", "RQ_kernel"])
+def test_searches_in_every_dimension_bucket(eng, D, kernel):
+    """The ascent kernels are compiled per padded dimension; one random model per bucket edge: the refined maxima of
+    the posterior mean (ppbo_mean_search) and of a sampled RFF utility (ppbo_rff_search, SE basis only) stay in the
+    box, carry the oracle's value at the returned point, are at least as high as the best raw candidate and beat a
+    dense random sample of the box."""
+    m, n_q = 4, 10
+    th = [0.1, 0.35 * np.sqrt(D), 0.7]
+    X = orc.synthetic_design(n_q, D, m=m, seed=100 + D)
+    N = X.shape[0]
+    S0 = orc.gram(X, th, kernel)
+    Sinv0 = orc.pd_inverse(S0)
+    f_init = np.random.default_rng(D).multivariate_normal(np.zeros(N), S0, method="cholesky")
+    f0, _ = orc.fit_fmap_trust_exact(f_init, Sinv0, m, th[0], gtol=1e-9)
+    post = eng.posterior(X, th, kernel, eng.pd_inverse(eng.gram(X, th, kernel)), f0, m)
+    alpha = host(post.alpha)                   # the device's Sigma^-1 f: the searches are checked, not the inverse
+    rng = np.random.default_rng(7 * D)
+    cand = np.vstack([rng.random((6000, D)), X])
+    mu_c, _ = orc.mean_grad(cand, X, th, alpha, kernel)
+    xs, vals = eng.mean_search(post, cand, K=16, sep=0.05, iters=100, tol=1e-9)
+    assert 1 <= len(vals) <= 16 and xs.shape == (len(vals), D) and np.all((xs >= 0) & (xs <= 1))
+    mu1, g1 = orc.mean_grad(xs, X, th, alpha, kernel)
+    assert np.abs(mu1 - vals).max() <= 1e-9 * np.abs(mu1).max() + 1e-14
+    assert vals.max() >= mu_c.max() - 1e-12 * max(1.0, np.abs(mu_c).max())
+    dense, _ = orc.mean_grad(rng.random((20000, D)), X, th, alpha, kernel)
+    assert vals.max() >= dense.max() - 1e-12
+    if kernel == "SE_kernel":
+        F = 96
+        W = np.random.default_rng(3).standard_normal((F, D)) / th[1]
+        b = np.random.default_rng(4).uniform(0, 2 * np.pi, F)
+        om = np.random.default_rng(5).standard_normal(F)
+        raw = orc.rff_score(cand, W, b, th[2], om)
+        xr, vr = eng.rff_search(cand, W, b, th[2], om, K=16, sep=0.05, iters=200, tol=1e-10)
+        assert 1 <= len(vr) <= 16 and np.all((xr >= 0) & (xr <= 1))
+        assert np.abs(orc.rff_score(xr, W, b, th[2], om) - vr).max() <= 1e-9 * np.abs(vr).max() + 1e-13
+        assert vr.max() >= raw.max() - 1e-12
+        assert vr.max() >= orc.rff_score(rng.random((20000, D)), W, b, th[2], om).max() - 1e-12
