@@ -201,3 +201,63 @@ def test_hartmann6_loop_reaches_the_optimum():
     gp, hist = run(queries=16, strategy="PCD", m=31, seed=0)
     assert gp.N == (6 + 16) * 32
     assert min(h["fx"] for h in hist) <= -3.0, hist
+
+
+_LOOP_CASES = [
+    # (strategy, alpha grid, kernel, incremental, theta optimisation after the initial queries / after each query)
+    ("PCD", "equispaced", "SE_kernel", False, False, False),
+    ("PCD", "Cauchy", "RQ_kernel", True, False, False),
+    ("PCD", "TGN", "SE_kernel", False, False, False),
+    ("EXT", "TGN", "RQ_kernel", True, False, False),
+    ("RAND", "Cauchy", "SE_kernel", False, True, False),
+    ("EI", "equispaced", "SE_kernel", False, False, False),
+    ("EI-FIXEDX", "equispaced", "RQ_kernel", False, False, False),
+    ("EXR", "TGN", "SE_kernel", True, False, False),
+    ("EI-EXT", "equispaced", "SE_kernel", False, False, False),
+    ("EI-EXT-FAST", "Cauchy", "SE_kernel", True, False, True),
+    ("EI-VARMAX", "equispaced", "SE_kernel", False, False, False),
+    ("EI-VARMAX-FAST", "TGN", "RQ_kernel", False, False, False),
+    ("COORDINATE-VARMAX", "equispaced", "SE_kernel", True, False, False),
+]
+
+
+@pytest.mark.parametrize("case", _LOOP_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_loop_runs_under_every_strategy_and_grid(case):
+    """The harness (ppbo_numerical_main.py:57-127) end to end on a 3-D quadratic bowl for every acquisition strategy
+    of PPBO_settings (ppbo_settings.py:56-98), each pseudo-observation grid distribution (feedback_processing.py:62-98),
+    both kernels, the incremental fit, and hyper-parameter optimisation on either schedule: bookkeeping invariants and
+    finite, in-bounds outputs -- the optimisation QUALITY of the strategies is tested elsewhere."""
+    from ppbo_amd.misc import hypercube_corners
+    from ppbo_amd.numerical_main import line_search_user, run_ppbo_loop
+    from ppbo_amd.ppbo_settings import PPBO_settings
+    strategy, grid, kernel, incremental, opt_after_init, opt_each = case
+    D, m, n_init, n_q = 3, 6, 3, 4
+    bounds = ((-1.0, 2.0), (0.0, 1.0), (-3.0, 1.0))
+    lo, hi = np.array([b[0] for b in bounds]), np.array([b[1] for b in bounds])
+    target = np.array([0.4, 0.8, -1.0])
+    np.random.seed(11)
+    st = PPBO_settings(D=D, bounds=bounds, xi_acquisition_function=strategy, m=m, theta_initial=[0.05, 0.4, 0.5],
+                       verbose=False, kernel=kernel, alpha_grid_distribution=grid, EI_EXR_mc_samples=60, EI_EXR_BO_maxiter=5)
+    xis = np.diag(hi)[:n_init]
+    xs = hypercube_corners(bounds)[:n_init].astype(float)
+    Ns = []
+    user = line_search_user(lambda P: ((P - target) ** 2).sum(axis=1), lo, hi, points=801)
+    results, xstars, mustars, gp = run_ppbo_loop(user, xis, xs, n_q, st, incremental=incremental,
+                                                 optimize_hyperparameters_after_initialization=opt_after_init,
+                                                 optimize_hyperparameters_after_each_iteration=opt_each,
+                                                 callback=lambda k, g: Ns.append(g.N))
+    n = n_init + n_q
+    assert results.shape == (n, 2 * D + 1) and xstars.shape == (n, D) and len(mustars) == n
+    assert Ns == [(m + 1) * (k + 1) for k in range(n)] and gp.N == (m + 1) * n
+    assert np.all(np.isfinite(results)) and np.all(np.isfinite(xstars[-n_q:])) and np.all(np.isfinite(mustars[-n_q:]))
+    pts = results[:, :D]
+    assert np.all(pts >= lo - 1e-9) and np.all(pts <= hi + 1e-9)              # every query point lies in the box
+    assert np.all(xstars[-n_q:] >= lo - 1e-9) and np.all(xstars[-n_q:] <= hi + 1e-9)
+    for k in range(n_init, n):                                                # the answer lies on the queried line
+        xi, a = results[k, D:2 * D], results[k, -1]
+        assert np.abs(xi).max() > 0
+        off = results[k, :D] - a * xi
+        assert np.allclose(off[xi != 0], 0.0, atol=1e-9) or strategy in ("EI", "EI-FIXEDX", "EXR", "EI-VARMAX", "EI-VARMAX-FAST", "COORDINATE-VARMAX")
+    assert len(gp.theta) == 3 and all(np.isfinite(gp.theta)) and gp.theta[0] > 0
+    if incremental:
+        assert gp.n_appends >= 1

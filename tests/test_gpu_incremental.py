@@ -165,3 +165,24 @@ def test_incremental_switched_on_late_falls_back_to_full_inversion(golden):
         gp.update_model()
     assert gp.n_full_inversions == n_init + 1 and gp.n_appends == 2
     assert np.abs(gp.Sigma @ gp.Sigma_inv - np.eye(gp.N)).max() < 1e-6
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_bordered_inverse_random_sizes(eng, seed):
+    """Random leading size (1 .. 900, every residue of the 64-row panel) and border width (1 .. 64 rows) on random
+    SPD matrices of random conditioning: inverse, L^-1 and L against LAPACK."""
+    rng = np.random.default_rng(50 + seed)
+    N1 = int(rng.integers(1, 901))
+    k = int(rng.integers(1, 65))
+    N = N1 + k
+    Q = rng.standard_normal((N, N))
+    A = Q @ Q.T / N + 10.0 ** rng.uniform(-3, 1) * np.eye(N)
+    Ai1, Li1, L1 = eng.pd_inverse_factors3(A[:N1, :N1].copy())
+    Ai, Li, L = eng.pd_inverse_append(A, Ai1, Li1, L1)
+    ref = np.linalg.inv(A)
+    Lref = np.linalg.cholesky(A)
+    tag = f"N1={N1} k={k}"
+    assert np.abs(host(Ai) - ref).max() <= 1e-9 * np.abs(ref).max(), tag
+    assert np.abs(np.tril(host(L)) - Lref).max() <= 1e-10 * np.abs(Lref).max(), tag
+    assert np.abs(np.tril(host(Li)) - np.linalg.inv(Lref)).max() <= 1e-9 * np.abs(np.linalg.inv(Lref)).max(), tag
+    assert np.abs(host(Ai) @ A - np.eye(N)).max() <= 1e-8, tag
