@@ -167,6 +167,10 @@ def test_incremental_switched_on_late_falls_back_to_full_inversion(golden):
     assert np.abs(gp.Sigma @ gp.Sigma_inv - np.eye(gp.N)).max() < 1e-6
 
 
+def host(t):
+    return t.cpu().numpy()
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_bordered_inverse_random_sizes(eng, seed):
     """Random leading size (1 .. 900, every residue of the 64-row panel) and border width (1 .. 64 rows) on random
