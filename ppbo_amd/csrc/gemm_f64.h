@@ -192,6 +192,148 @@ __device__ __forceinline__ void mainloop_impl(const double* __restrict__ A, int 
   }
 }
 
+// ---- the lean main loop (every tile of the launch in bounds and aligned) --------------------------------------
+// On CDNA4 a wavefront's non-MFMA VALU instructions do not overlap with the fp64 MFMAs of its SIMD (measured: one
+// extra VALU op per MFMA costs 7 % of the matrix-core rate), and the generic loop above spends ~30 of them per
+// 16-deep chunk on 64-bit global addresses, LDS buffer toggling and per-lane tests of the wave-uniform K limit
+// (PMC: 1.03 VALU per MFMA; 0.85 of the MFMA peak).  Here the loop body has none:
+//   * operand tiles are fetched with buffer loads: the descriptor's base (SGPRs) walks along K on the SALU, the
+//     per-thread byte offset is a 32-bit VGPR fixed before the loop;
+//   * the loop is unrolled over the two LDS buffers, the B image comes first in a buffer so that every fragment of
+//     either buffer is within the 16-bit immediate of ds_read_b64 from ONE lane-constant base per operand (reads are
+//     volatile so that the load/store optimizer does not pair them into ds_read2 + a VALU base adjustment);
+//   * the K limit of the wavefront is a scalar.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int LAY, int ROWS, int NT>
+__device__ __forceinline__ unsigned elem_byte_off(int ld, int p) {
+  int r, k;
+  tile_coord<LAY, ROWS, NT>(p, r, k);
+  return (unsigned)(((LAY == KC) ? r * ld + k : k * ld + r) * 8);
+}
+
+__device__ __forceinline__ double2 buffer_load2(const double* __restrict__ sbase, unsigned byte_off) {
+  // raw buffer, stride 0, no bound (the host checked the tiles): word 3 = 32-bit data format (CDNA3/4 encoding)
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(sbase), 0, -1, 0x00020000);
+  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
+typedef const volatile double __attribute__((address_space(3))) * lds_vptr;
+__device__ __forceinline__ double lds_vread(int off_doubles) {
+  return *((lds_vptr)(&lds_dyn[0]) + off_doubles);      // stays a ds_read_b64: the cast keeps the LDS address space
+}
+
+template <class C, int ALAY, int BLAY, int CUR>
+__device__ __forceinline__ void lean_chunk(const double* __restrict__ pa, const double* __restrict__ pb,
+                                           const unsigned (&offA)[C::BM * 8 / C::NT], const unsigned (&offB)[C::BN * 8 / C::NT],
+                                           int a_lane, int b_lane, int kleft, double4_t acc[C::TM][C::TN]) {
+  constexpr int BUF = C::IMG_A + C::IMG_B;          // lean layout of buffer b: B image at b*BUF, A image behind it
+  constexpr int PA = C::BM * 8 / C::NT, PB = C::BN * 8 / C::NT;
+  constexpr int A_I = (ALAY == KC) ? 16 * KC_LD : 16;
+  constexpr int B_J = (BLAY == KC) ? 16 * KC_LD : 16;
+  constexpr int A_K = (ALAY == KC) ? 4 : 4 * (C::BM + 16);
+  constexpr int B_K = (BLAY == KC) ? 4 : 4 * (C::BN + 16);
+  constexpr int RA = CUR * BUF + C::IMG_B, RB = CUR * BUF;              // read from this buffer ...
+  constexpr int WA = (1 - CUR) * BUF + C::IMG_B, WB = (1 - CUR) * BUF;  // ... stage the next chunk into the other
+  double2 ra[PA], rb[PB];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) ra[p] = buffer_load2(pa, offA[p]);
+#pragma unroll
+  for (int p = 0; p < PB; ++p) rb[p] = buffer_load2(pb, offB[p]);
+  if (kleft > 0) {                     // scalar: this wavefront's rows of A are zero from k_wave_end on
+    double a0[C::TM], b0[C::TN], a1[C::TM], b1[C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) a0[i] = lds_vread(a_lane + RA + i * A_I);
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) b0[j] = lds_vread(b_lane + RB + j * B_J);
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) a1[i] = lds_vread(a_lane + RA + A_K + i * A_I);
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) b1[j] = lds_vread(b_lane + RB + B_K + j * B_J);
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+    if (kleft > 4) {
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i) a0[i] = lds_vread(a_lane + RA + 2 * A_K + i * A_I);
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) b0[j] = lds_vread(b_lane + RB + 2 * B_K + j * B_J);
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    }
+    if (kleft > 8) {
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i) a1[i] = lds_vread(a_lane + RA + 3 * A_K + i * A_I);
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) b1[j] = lds_vread(b_lane + RB + 3 * B_K + j * B_J);
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+    }
+    if (kleft > 12) {
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PA; ++p) store_elem<ALAY, C::BM, C::NT>(WA, p, ra[p]);
+#pragma unroll
+  for (int p = 0; p < PB; ++p) store_elem<BLAY, C::BN, C::NT>(WB, p, rb[p]);
+  __syncthreads();
+}
+
+template <class C, int ALAY, int BLAY>
+__device__ __forceinline__ void mainloop_lean(const double* __restrict__ A, int lda, const double* __restrict__ B,
+                                              int ldb, int m0, int n0, int kbeg, int kend,
+                                              double4_t acc[C::TM][C::TN], int k_wave_end) {
+  constexpr int PA = C::BM * 8 / C::NT, PB = C::BN * 8 / C::NT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int nk = (kend - kbeg) / BK;
+  const int a_lane = frag_off<ALAY, C::BM>(wm * C::TM * 16 + lr, lk);
+  const int b_lane = frag_off<BLAY, C::BN>(wn * C::TN * 16 + lr, lk);
+  unsigned offA[PA], offB[PB];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) offA[p] = elem_byte_off<ALAY, C::BM, C::NT>(lda, p);
+#pragma unroll
+  for (int p = 0; p < PB; ++p) offB[p] = elem_byte_off<BLAY, C::BN, C::NT>(ldb, p);
+  // scalar tile origins and per-chunk strides (doubles)
+  const double* pa = (ALAY == KC) ? A + (size_t)m0 * lda + kbeg : A + (size_t)kbeg * lda + m0;
+  const double* pb = (BLAY == KC) ? B + (size_t)n0 * ldb + kbeg : B + (size_t)kbeg * ldb + n0;
+  const size_t sa = (ALAY == KC) ? (size_t)BK : (size_t)BK * lda;
+  const size_t sb = (BLAY == KC) ? (size_t)BK : (size_t)BK * ldb;
+  int kleft = __builtin_amdgcn_readfirstlane(k_wave_end < kend ? k_wave_end : kend) - kbeg;   // depth this wavefront still multiplies
+  {
+    double2 ra[PA], rb[PB];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) ra[p] = buffer_load2(pa, offA[p]);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) rb[p] = buffer_load2(pb, offB[p]);
+#pragma unroll
+    for (int p = 0; p < PA; ++p) store_elem<ALAY, C::BM, C::NT>(C::IMG_B, p, ra[p]);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) store_elem<BLAY, C::BN, C::NT>(0, p, rb[p]);
+  }
+  __syncthreads();
+  // chunk kt computes from buffer kt & 1 and stages chunk kt + 1 (the last one re-reads itself: branch-free body)
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 1 < nk) { pa += sa; pb += sb; }
+    lean_chunk<C, ALAY, BLAY, 0>(pa, pb, offA, offB, a_lane, b_lane, kleft, acc);
+    kleft -= BK;
+    if (kt + 1 >= nk) break;
+    if (kt + 2 < nk) { pa += sa; pb += sb; }
+    lean_chunk<C, ALAY, BLAY, 1>(pa, pb, offA, offB, a_lane, b_lane, kleft, acc);
+    kleft -= BK;
+  }
+}
+
 // ALWAYS_FAST: the host has verified that every tile of the launch is in bounds and aligned,
 // so the guarded (scalar, zero-filling) loop is not even compiled into the kernel.
 template <class C, int ALAY, int BLAY, bool ALWAYS_FAST = false>
@@ -199,12 +341,17 @@ __device__ __forceinline__ void mainloop(const double* __restrict__ A, int lda, 
                                          int ldb, int M, int N, int m0, int n0, int kbeg, int kend,
                                          double4_t acc[C::TM][C::TN], int k_wave_end = 0x7fffffff) {
   if (kend <= kbeg) return;
+  // the lean loop addresses a tile by 32-bit byte offsets: (tile rows or 16) * ld * 8 must stay below 2^31
+  const bool small_ld = (size_t)((ALAY == KC) ? C::BM : BK) * (size_t)lda < ((size_t)1 << 28) &&
+                        (size_t)((BLAY == KC) ? C::BN : BK) * (size_t)ldb < ((size_t)1 << 28);
   if (ALWAYS_FAST) {
-    mainloop_impl<C, ALAY, BLAY, true>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc, k_wave_end);
+    if (small_ld) mainloop_lean<C, ALAY, BLAY>(A, lda, B, ldb, m0, n0, kbeg, kend, acc, k_wave_end);
+    else mainloop_impl<C, ALAY, BLAY, true>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc, k_wave_end);
     return;
   }
   const bool fast = tile_fast<C::BM>(A, lda, m0, kbeg, kend, M) && tile_fast<C::BN>(B, ldb, n0, kbeg, kend, N);
-  if (fast) mainloop_impl<C, ALAY, BLAY, true>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc, k_wave_end);
+  if (fast && small_ld) mainloop_lean<C, ALAY, BLAY>(A, lda, B, ldb, m0, n0, kbeg, kend, acc, k_wave_end);
+  else if (fast) mainloop_impl<C, ALAY, BLAY, true>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc, k_wave_end);
   else mainloop_impl<C, ALAY, BLAY, false>(A, lda, B, ldb, M, N, m0, n0, kbeg, kend, acc, k_wave_end);
 }
 
