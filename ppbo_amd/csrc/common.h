@@ -35,7 +35,7 @@ struct ppbo_ctx {
   // kernels whose dynamic-LDS limit has been raised on THIS ctx's device (hipFuncSetAttribute is per device)
   std::vector<const void*> lds_raised;
   // tuning knobs, read from the environment once per ctx (ppbo_ctx_create); defaults = measured best
-  int qf_variant = 2, qf_order = 258, qf_prio = 0, potrf_gen = 3, rff_nt = 0, gram_variant = -1, rff_score_mfma = 1;
+  int qf_variant = 2, qf_order = 258, potrf_gen = 3, rff_nt = 0, gram_variant = -1, rff_score_mfma = 1;
   ppbo_dist_state* dist = nullptr;   // set by ppbo_dist_init
 };
 

@@ -274,17 +274,24 @@ __device__ __forceinline__ void lean_chunk(const double* __restrict__ pa, const 
 #pragma unroll
         for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
     }
+    // the next chunk goes to the other buffer BEFORE the last MFMA group: the stores' latency and the wait at the
+    // barrier run under those eight MFMAs instead of after them
+#pragma unroll
+    for (int p = 0; p < PA; ++p) store_elem<ALAY, C::BM, C::NT>(WA, p, ra[p]);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) store_elem<BLAY, C::BN, C::NT>(WB, p, rb[p]);
     if (kleft > 12) {
 #pragma unroll
       for (int i = 0; i < C::TM; ++i)
 #pragma unroll
         for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
     }
+  } else {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) store_elem<ALAY, C::BM, C::NT>(WA, p, ra[p]);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) store_elem<BLAY, C::BN, C::NT>(WB, p, rb[p]);
   }
-#pragma unroll
-  for (int p = 0; p < PA; ++p) store_elem<ALAY, C::BM, C::NT>(WA, p, ra[p]);
-#pragma unroll
-  for (int p = 0; p < PB; ++p) store_elem<BLAY, C::BN, C::NT>(WB, p, rb[p]);
   __syncthreads();
 }
 

@@ -193,15 +193,7 @@ template <class C, int MINW, bool ALWAYS_FAST>
 __global__ __launch_bounds__(C::NT, MINW) void quadform_kernel(const double* __restrict__ G, int N,
                                                                const double* __restrict__ Kt, int ldk, int M,
                                                                int tri_block, double* __restrict__ slab, int ntm,
-                                                               int ntn, int swizzle, int prio_mode) {
-  // asymmetric wave priority between the two workgroups that share a CU (experiment, PPBO_QF_PRIO)
-  if (prio_mode == 1) {
-    if (__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(3);   // HW_ID.tg_id parity
-  } else if (prio_mode == 2) {
-    if ((__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) >> 1) & 1) __builtin_amdgcn_s_setprio(3);   // HW_ID.wave_id bit 1
-  } else if (prio_mode == 3) {
-    if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(3);
-  }
+                                                               int ntn, int swizzle) {
   int id = blockIdx.x;
   if (swizzle & 1) {                   // XCD-aware: consecutive logical ids share an XCD / L2
     const int per = gridDim.x >> 3;
@@ -274,8 +266,8 @@ int launch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, int
   // every tile in bounds, 16-byte aligned, and every K range a multiple of 16?
   const bool fast = (N % C::BM == 0) && (Mc % C::BN == 0) && (N % 2 == 0) && (ldk % 2 == 0) && (mblk % 16 == 0 || mblk == 1 || (C::BM % mblk == 0)) &&
                     ((reinterpret_cast<uintptr_t>(G) & 15) == 0) && ((reinterpret_cast<uintptr_t>(Kt) & 15) == 0);
-  if (fast) quadform_kernel<C, MINW, true><<<grid, C::NT, lds, s>>>(G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn, swz, ctx->qf_prio);
-  else quadform_kernel<C, MINW, false><<<grid, C::NT, lds, s>>>(G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn, swz, ctx->qf_prio);
+  if (fast) quadform_kernel<C, MINW, true><<<grid, C::NT, lds, s>>>(G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn, swz);
+  else quadform_kernel<C, MINW, false><<<grid, C::NT, lds, s>>>(G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn, swz);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
