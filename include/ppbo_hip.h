@@ -269,6 +269,12 @@ int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
                   double shrink, const double* d_z, int S, double mustar, double jitter,
                   double* d_ei, double* d_varmax, void* stream);
 
+/* standard normal draws for the Monte-Carlo acquisitions, generated on the device: d_out[n] = a pure function of
+ * (seed, index) (Philox-4x32-10 + Box-Muller), i.e. reproducible and independent of the launch geometry.  Replaces
+ * the np.random.multivariate_normal / standard_normal draws of src/acquisition.py:76,174 where the caller does not
+ * need NumPy's own stream (the batched searches; EI() / varmax() called with explicit draws keep the caller's z). */
+int ppbo_randn(ppbo_ctx* ctx, uint64_t seed, double* d_out, int64_t n, void* stream);
+
 /* ---- K7/K8/K9: random Fourier features --------------------------------------
  * ppbo_rff_project replaces Hsampler.phiVec/update_phi_X
  *   (src/random_fourier_sampler.py:45-47,57-58): d_Phi[F,N] = sqrt(2 sf^2/F) cos(W X^T + b).

@@ -456,6 +456,13 @@ class Engine:
         self._check(rc, "ppbo_rff_score")
         return sc, bv.value, bi.value
 
+    def randn(self, seed, *shape):
+        """Standard normal draws generated on the device (ppbo_randn): a pure function of (seed, index)."""
+        out = self.empty(*shape)
+        rc = self.lib.ppbo_randn(self.ctx, int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(out), out.numel(), self._stream())
+        self._check(rc, "ppbo_randn")
+        return out
+
     def rff_search(self, cand, W, b, sigma_f, omega, K=32, sep=0.05, iters=200, tol=1e-10):
         """Device-resident maximiser of phi(x)^T omega over the rows of `cand` (ppbo_rff_search): refined maxima
         x[found, D], values[found] as NumPy arrays."""

@@ -119,3 +119,30 @@ def test_single_point_objectives(golden):
     np.random.seed(4); a = acq.EI_fixed_x_to_maximize(np.array([[0.7]]), xs, xi_dims, gp, 200)
     np.random.seed(4); b = acq.EI(xi_, xs, gp, 200)
     assert a == b and np.isfinite(a)
+
+
+def test_device_normal_draws(eng):
+    """ppbo_randn: a pure function of (seed, index) -- same seed same bits, a prefix of a longer request is the shorter
+    one, different seeds differ -- with the moments and the distribution function of N(0, 1) (Kolmogorov-Smirnov at
+    2^20 draws; the 1e-3 critical value is 1.95 / sqrt(n))."""
+    from scipy.special import ndtr
+    n = 1 << 20
+    a = host(eng.randn(123, n))
+    b = host(eng.randn(123, n))
+    assert np.array_equal(a, b)
+    assert np.array_equal(host(eng.randn(123, 1001)), a[:1001])           # odd length: the last pair is cut, not shifted
+    c = host(eng.randn(124, n))
+    assert not np.array_equal(a, c) and abs(np.corrcoef(a, c)[0, 1]) < 5e-3
+    assert np.all(np.isfinite(a))
+    assert abs(a.mean()) < 5.0 / np.sqrt(n) and abs(a.var() - 1.0) < 5.0 * np.sqrt(2.0 / n)
+    assert abs((a ** 3).mean()) < 0.02 and abs((a ** 4).mean() - 3.0) < 0.05
+    xs = np.sort(a)
+    ks = np.abs(ndtr(xs) - (np.arange(1, n + 1) - 0.5) / n).max()
+    assert ks < 1.95 / np.sqrt(n), ks
+    assert abs(np.corrcoef(a[0::2], a[1::2])[0, 1]) < 5e-3                 # the two outputs of a Box-Muller pair
+    assert abs(np.corrcoef(a[:-2], a[2:])[0, 1]) < 5e-3                    # neighbouring counters
+    m = host(eng.randn(7, 300, 70))
+    assert m.shape == (300, 70)
+    with pytest.raises(RuntimeError):
+        eng.lib.ppbo_randn.restype  # noqa: B018  (binding exists)
+        eng._check(eng.lib.ppbo_randn(eng.ctx, 1, None, 10, eng._stream()), "ppbo_randn")
