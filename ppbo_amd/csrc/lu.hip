@@ -3,9 +3,14 @@
 //   sign*logdet.  P and L contribute 0 (logdet 0), so the value is  sign(prod diag U) * sum log|diag U|,
 //   which depends on the pivot sequence; LAPACK's rule is reproduced: pivot = first row of maximal
 //   |entry| in the column at and below the diagonal.
-// Right-looking blocked LU, NB = 32:
+// Right-looking blocked LU, NB = 16:
 //   getrf_panel   one 1024-thread workgroup: per column an argmax reduction (first index wins ties),
-//                 the row swap inside the panel, scaling and the rank-1 update of the panel columns
+//                 the row swap inside the panel, scaling and the rank-1 update of the panel columns.
+//                 Up to 2048 rows below the diagonal the panel lives in REGISTERS for the whole factorization
+//                 (getrf_panel_reg_kernel: a thread owns one or two rows of 16 entries; the pivot row and the row it
+//                 displaces travel through LDS) -- the memory-resident form (getrf_panel_kernel, kept for taller
+//                 panels) pays ~5 dependent global round trips per column, 20 us x N columns = 40 of the 57 ms of
+//                 one evidence at N = 2048
 //   laswp         the panel's row swaps applied to all columns outside it (one lane per column)
 //   trsm_unit     U12 = L11^-1 A12, one lane per column, L11 broadcast from LDS
 //   dgemm         A22 -= L21 U12 on the fp64 MFMA engine
@@ -14,7 +19,7 @@
 
 namespace {
 
-constexpr int LNB = 32;
+constexpr int LNB = 16;
 
 struct PivRec {
   double val;
@@ -79,6 +84,105 @@ __global__ __launch_bounds__(1024) void getrf_panel_kernel(double* __restrict__ 
       }
     }
     __syncthreads();
+  }
+}
+
+// The panel in registers: thread t owns rows k0 + t + 1024 i (i < RPT) of the panel's nb <= 16 columns.
+template <int RPT>
+__global__ __launch_bounds__(1024) void getrf_panel_reg_kernel(double* __restrict__ A, int lda, int N, int k0, int nb,
+                                                               int* __restrict__ ipiv, int* __restrict__ info) {
+  __shared__ PivRec sh[16];
+  __shared__ double rowc[LNB], prow[LNB];    // the row at the diagonal before the swap; the pivot row
+  __shared__ int s_p;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  double a[RPT][LNB];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = k0 + t + 1024 * i;
+#pragma unroll
+    for (int c = 0; c < LNB; ++c) a[i][c] = (r < N && c < nb) ? A[(size_t)r * lda + k0 + c] : 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < LNB; ++j) {
+    if (j < nb) {             // uniform; a `break` here would keep the loop from unrolling (a[][j] must be static)
+    const int col = k0 + j;
+    PivRec best{0.0, -1};
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = k0 + t + 1024 * i;
+      if (r >= col && r < N) {
+        const double v = fabs(a[i][j]);
+        if (best.idx < 0 || v > best.val) { best.val = v; best.idx = r; }   // ascending r: strict > keeps the first
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      PivRec other;
+      other.val = __shfl_xor(best.val, o, 64);
+      other.idx = __shfl_xor(best.idx, o, 64);
+      best = piv_merge(best, other);
+    }
+    if (lane == 0) sh[w] = best;
+    __syncthreads();
+    if (t == 0) {
+      PivRec b = sh[0];
+      for (int k = 1; k < 16; ++k) b = piv_merge(b, sh[k]);
+      s_p = b.idx;
+      ipiv[col] = b.idx;
+      if (b.val == 0.0 && *info == 0) *info = col + 1;
+    }
+    __syncthreads();
+    const int p = s_p;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = k0 + t + 1024 * i;
+      if (r == col) {
+#pragma unroll
+        for (int c = 0; c < LNB; ++c) rowc[c] = a[i][c];
+      }
+      if (r == p) {
+#pragma unroll
+        for (int c = 0; c < LNB; ++c) prow[c] = a[i][c];
+      }
+    }
+    __syncthreads();
+    if (p != col) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int r = k0 + t + 1024 * i;
+        if (r == col) {
+#pragma unroll
+          for (int c = 0; c < LNB; ++c) a[i][c] = prow[c];
+        } else if (r == p) {
+#pragma unroll
+          for (int c = 0; c < LNB; ++c) a[i][c] = rowc[c];
+        }
+      }
+    }
+    const double piv = prow[j];
+    if (piv != 0.0) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int r = k0 + t + 1024 * i;
+        if (r > col && r < N) {
+          const double l = a[i][j] / piv;
+          a[i][j] = l;
+#pragma unroll
+          for (int c = j + 1; c < LNB; ++c) a[i][c] -= l * prow[c];
+        }
+      }
+    }
+    __syncthreads();          // rowc / prow / sh are rewritten by the next column
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = k0 + t + 1024 * i;
+    if (r < N) {
+#pragma unroll
+      for (int c = 0; c < LNB; ++c)
+        if (c < nb) A[(size_t)r * lda + k0 + c] = a[i][c];
+    }
   }
 }
 
@@ -183,7 +287,9 @@ int ppbo_lu_slogdet(ppbo_ctx* ctx, double* d_A, int N, int lda, double* h_u_sign
   PPBO_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(int), s));
   for (int k0 = 0; k0 < N; k0 += LNB) {
     const int nb = (N - k0 < LNB) ? (N - k0) : LNB;
-    getrf_panel_kernel<<<1, 1024, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv, d_info);
+    if (N - k0 <= 1024) getrf_panel_reg_kernel<1><<<1, 1024, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv, d_info);
+    else if (N - k0 <= 2048) getrf_panel_reg_kernel<2><<<1, 1024, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv, d_info);
+    else getrf_panel_kernel<<<1, 1024, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv, d_info);
     if (N - nb > 0) laswp_kernel<<<(N - nb + 255) / 256, 256, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv);
     const int rest = N - k0 - nb;
     if (rest > 0) {

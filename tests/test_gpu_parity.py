@@ -476,7 +476,7 @@ def test_c5_size_camphor_properties(eng):
 
 
 # ---------------------------------------------------------------- a-9: LU / evidence
-@pytest.mark.parametrize("N", [1, 5, 31, 32, 33, 64, 100, 257, 513, 1024])
+@pytest.mark.parametrize("N", [1, 5, 15, 16, 17, 31, 32, 33, 64, 100, 257, 513, 1024, 1025, 1500, 2048, 2300])
 def test_lu_slogdet_matches_lapack_pivoting(eng, N):
     import scipy.linalg
     rng = np.random.default_rng(N)
