@@ -87,14 +87,112 @@ __global__ __launch_bounds__(1024) void getrf_panel_kernel(double* __restrict__ 
   }
 }
 
+// (value, index) argmax over a wavefront without the LDS crossbar: four DPP steps inside each row of 16 lanes
+// (xor 1, xor 2, row_half_mirror, row_mirror), then the four row winners through scalar registers.  piv_merge is
+// a max under a total order (larger |value|, then smaller index), so any reduction order gives the same winner.
+template <int CTRL>
+__device__ __forceinline__ PivRec piv_dpp_step(PivRec a) {
+  PivRec o;
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(a.val), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(a.val), CTRL, 0xF, 0xF, true);
+  o.idx = __builtin_amdgcn_mov_dpp(a.idx, CTRL, 0xF, 0xF, true);
+  o.val = __hiloint2double(hi, lo);
+  return piv_merge(a, o);
+}
+__device__ __forceinline__ PivRec wave_piv(PivRec a) {
+  a = piv_dpp_step<0xB1>(a);
+  a = piv_dpp_step<0x4E>(a);
+  a = piv_dpp_step<0x141>(a);
+  a = piv_dpp_step<0x140>(a);
+  PivRec r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r[k].val = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a.val), 16 * k),
+                                __builtin_amdgcn_readlane(__double2loint(a.val), 16 * k));
+    r[k].idx = __builtin_amdgcn_readlane(a.idx, 16 * k);
+  }
+  return piv_merge(piv_merge(r[0], r[1]), piv_merge(r[2], r[3]));
+}
+
+// One column step of the register-resident panel (J is a template parameter: every index into a[][] is static, or the
+// panel would be demoted to scratch).
+template <int RPT, int J>
+__device__ __forceinline__ void lu_reg_column(double (&a)[RPT][LNB], int N, int k0, int* __restrict__ ipiv,
+                                              int* __restrict__ info, PivRec* sh, double* rowc, double* prow) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int col = k0 + J;
+  PivRec best{0.0, -1};
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = k0 + t + 1024 * i;
+    if (r >= col && r < N) {
+      const double v = fabs(a[i][J]);
+      if (best.idx < 0 || v > best.val) { best.val = v; best.idx = r; }   // ascending r: strict > keeps the first
+    }
+  }
+  best = wave_piv(best);
+  if (lane == 0) sh[w] = best;
+  __syncthreads();
+  // every wavefront merges the 16 records itself (lane l < 16 takes record l): no serial merge by one thread, no
+  // second barrier to publish the winner
+  PivRec mine{0.0, -1};
+  if (lane < 16) mine = sh[lane];
+  const PivRec win = wave_piv(mine);
+  if (t == 0) {
+    ipiv[col] = win.idx;
+    if (win.val == 0.0 && *info == 0) *info = col + 1;
+  }
+  const int p = win.idx;
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int r = k0 + t + 1024 * i;
+    if (r == col) {
+#pragma unroll
+      for (int c = 0; c < LNB; ++c) rowc[c] = a[i][c];
+    }
+    if (r == p) {
+#pragma unroll
+      for (int c = 0; c < LNB; ++c) prow[c] = a[i][c];
+    }
+  }
+  __syncthreads();
+  if (p != col) {
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = k0 + t + 1024 * i;
+      if (r == col) {
+#pragma unroll
+        for (int c = 0; c < LNB; ++c) a[i][c] = prow[c];
+      } else if (r == p) {
+#pragma unroll
+        for (int c = 0; c < LNB; ++c) a[i][c] = rowc[c];
+      }
+    }
+  }
+  const double piv = prow[J];
+  if (piv != 0.0) {
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = k0 + t + 1024 * i;
+      if (r > col && r < N) {
+        const double l = a[i][J] / piv;
+        a[i][J] = l;
+#pragma unroll
+        for (int c = J + 1; c < LNB; ++c) a[i][c] -= l * prow[c];
+      }
+    }
+  }
+  // no barrier here: the next column rewrites sh only after every thread has passed the barrier above (all reads of
+  // sh precede it), and rowc / prow only after the next column's first barrier (all reads of them precede that)
+}
+
 // The panel in registers: thread t owns rows k0 + t + 1024 i (i < RPT) of the panel's nb <= 16 columns.
 template <int RPT>
-__global__ __launch_bounds__(1024) void getrf_panel_reg_kernel(double* __restrict__ A, int lda, int N, int k0, int nb,
-                                                               int* __restrict__ ipiv, int* __restrict__ info) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void getrf_panel_reg_kernel(
+    double* __restrict__ A, int lda, int N, int k0, int nb, int* __restrict__ ipiv, int* __restrict__ info) {
   __shared__ PivRec sh[16];
   __shared__ double rowc[LNB], prow[LNB];    // the row at the diagonal before the swap; the pivot row
-  __shared__ int s_p;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x;
   double a[RPT][LNB];
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
@@ -102,79 +200,11 @@ __global__ __launch_bounds__(1024) void getrf_panel_reg_kernel(double* __restric
 #pragma unroll
     for (int c = 0; c < LNB; ++c) a[i][c] = (r < N && c < nb) ? A[(size_t)r * lda + k0 + c] : 0.0;
   }
-#pragma unroll
-  for (int j = 0; j < LNB; ++j) {
-    if (j < nb) {             // uniform; a `break` here would keep the loop from unrolling (a[][j] must be static)
-    const int col = k0 + j;
-    PivRec best{0.0, -1};
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      const int r = k0 + t + 1024 * i;
-      if (r >= col && r < N) {
-        const double v = fabs(a[i][j]);
-        if (best.idx < 0 || v > best.val) { best.val = v; best.idx = r; }   // ascending r: strict > keeps the first
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      PivRec other;
-      other.val = __shfl_xor(best.val, o, 64);
-      other.idx = __shfl_xor(best.idx, o, 64);
-      best = piv_merge(best, other);
-    }
-    if (lane == 0) sh[w] = best;
-    __syncthreads();
-    if (t == 0) {
-      PivRec b = sh[0];
-      for (int k = 1; k < 16; ++k) b = piv_merge(b, sh[k]);
-      s_p = b.idx;
-      ipiv[col] = b.idx;
-      if (b.val == 0.0 && *info == 0) *info = col + 1;
-    }
-    __syncthreads();
-    const int p = s_p;
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      const int r = k0 + t + 1024 * i;
-      if (r == col) {
-#pragma unroll
-        for (int c = 0; c < LNB; ++c) rowc[c] = a[i][c];
-      }
-      if (r == p) {
-#pragma unroll
-        for (int c = 0; c < LNB; ++c) prow[c] = a[i][c];
-      }
-    }
-    __syncthreads();
-    if (p != col) {
-#pragma unroll
-      for (int i = 0; i < RPT; ++i) {
-        const int r = k0 + t + 1024 * i;
-        if (r == col) {
-#pragma unroll
-          for (int c = 0; c < LNB; ++c) a[i][c] = prow[c];
-        } else if (r == p) {
-#pragma unroll
-          for (int c = 0; c < LNB; ++c) a[i][c] = rowc[c];
-        }
-      }
-    }
-    const double piv = prow[j];
-    if (piv != 0.0) {
-#pragma unroll
-      for (int i = 0; i < RPT; ++i) {
-        const int r = k0 + t + 1024 * i;
-        if (r > col && r < N) {
-          const double l = a[i][j] / piv;
-          a[i][j] = l;
-#pragma unroll
-          for (int c = j + 1; c < LNB; ++c) a[i][c] -= l * prow[c];
-        }
-      }
-    }
-    __syncthreads();          // rowc / prow / sh are rewritten by the next column
-    }
-  }
+#define LU_COL(J) if (J < nb) lu_reg_column<RPT, J>(a, N, k0, ipiv, info, sh, rowc, prow);     /* nb is uniform */
+  LU_COL(0) LU_COL(1) LU_COL(2) LU_COL(3) LU_COL(4) LU_COL(5) LU_COL(6) LU_COL(7)
+  LU_COL(8) LU_COL(9) LU_COL(10) LU_COL(11) LU_COL(12) LU_COL(13) LU_COL(14) LU_COL(15)
+#undef LU_COL
+  static_assert(LNB == 16, "LU_COL list");
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     const int r = k0 + t + 1024 * i;
