@@ -619,6 +619,39 @@ def test_line_acq_long_grids(eng, golden, G):
         eng.line_acq(post, np.zeros((1, 129, D)), rng.standard_normal((10, 129)), mustar)
 
 
+@pytest.mark.parametrize("B,G,S", [(1, 1, 1), (1, 70, 4800), (2, 15, 63), (3, 16, 64), (5, 17, 65), (7, 33, 1000), (40, 70, 150),
+                                   (64, 70, 1201), (300, 48, 97), (530, 20, 40)])
+def test_line_acq_shapes(eng, golden, B, G, S):
+    """The Monte-Carlo kernel splits the draws of a line over workgroups when the batch is small, pads grids to
+    multiples of 16 and draws to multiples of 16 per split, and chunks batches above 512 lines: every combination
+    of few / many lines, ragged G and ragged S against the oracle on the same draws (a few lines per case)."""
+    g = golden("smoke")
+    post, _ = _posterior(eng, g)
+    D = int(g["D"])
+    rng = np.random.default_rng(1000 * B + 10 * G + S)
+    al = np.sort(rng.random(G))
+    xis = np.zeros((B, D)); xis[np.arange(B), rng.integers(0, D, B)] = 1.0
+    xs = rng.random((B, D)) * (xis == 0)
+    grid = al[None, :, None] * xis[:, None, :] + xs[:, None, :]
+    z = rng.standard_normal((S, G))
+    sf2 = float(g["theta"][2]) ** 2
+    mustar, jit = float(g["line_mustar"]), 1e-9 * sf2
+    ei, vm = eng.line_acq(post, grid, z, mustar, jitter=jit)
+    ei, vm = host(ei), host(vm)
+    assert ei.shape == (B,) and np.all(np.isfinite(ei)) and np.all(np.isfinite(vm)) and np.all(ei >= 0) and np.all(vm >= -1e-12 * sf2)
+    for b in sorted(set([0, B // 2, B - 1])):
+        mu_b, cov_b = eng.predict_cov(post, grid[b])
+        e0 = orc.line_ei(host(mu_b), host(cov_b), z, mustar, jitter=jit)
+        v0 = orc.line_varmax(host(mu_b), host(cov_b), z, jitter=jit)
+        assert abs(ei[b] - e0) <= 1e-6 * max(abs(e0), 1e-3 * np.sqrt(sf2)), (b, ei[b], e0)
+        assert abs(vm[b] - v0) <= 1e-5 * max(abs(v0), 1e-6 * sf2), (b, vm[b], v0)
+    # identical lines give identical values wherever they sit in the batch (split / chunk independent)
+    if B >= 3:
+        grid2 = grid.copy(); grid2[-1] = grid[0]
+        ei2, vm2 = eng.line_acq(post, grid2, z, mustar, jitter=jit)
+        assert host(ei2)[-1] == host(ei2)[0] and host(vm2)[-1] == host(vm2)[0]
+
+
 @pytest.mark.parametrize("D", [1, 11, 13, 17, 23, 24, 30, 33, 47, 48, 50, 64])
 @pytest.mark.parametrize("kernel", ["SE_kernel", "RQ_kernel"])
 def test_every_dimension_bucket(eng, D, kernel):
