@@ -387,17 +387,21 @@ class Engine:
         self._check(rc, "ppbo_mean_grad")
         return mu, grad
 
-    def mean_search(self, post: Posterior, cand, K=32, sep=0.05, iters=100, tol=1e-9):
+    def mean_search(self, post: Posterior, cand, K=32, sep=0.05, iters=100, tol=1e-9, sync=True):
         """Device-resident maximiser of the posterior mean over the rows of `cand` (ppbo_mean_search): returns the
-        refined maxima x[found, D], mu[found] as NumPy arrays."""
+        refined maxima x[found, D], mu[found] as NumPy arrays.  sync=False only enqueues (h_found = NULL: nothing
+        synchronises) and returns the device tensors x[K, D], mu[K] -- rows that found no start carry mu = -inf -- so
+        that several searches can be queued behind each other and read back together."""
         cand = self.dev(cand)
         M, D = cand.shape
         md = self._model(post, False)
         xs, mus = self.empty(K, D), self.empty(K)
         found = C.c_int(0)
         rc = self.lib.ppbo_mean_search(self.ctx, C.byref(md), _ptr(cand), M, int(K), float(sep), int(iters), float(tol),
-                                       _ptr(xs), _ptr(mus), C.byref(found), self._stream())
+                                       _ptr(xs), _ptr(mus), C.byref(found) if sync else None, self._stream())
         self._check(rc, "ppbo_mean_search")
+        if not sync:
+            return xs, mus
         n = found.value
         return xs[:n].cpu().numpy(), mus[:n].cpu().numpy()
 

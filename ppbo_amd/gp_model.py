@@ -603,26 +603,41 @@ class GPModel:
         work = torch.empty((M + N + 1, D), dtype=torch.float64, device=self.eng.device)
         work[M:M + N].copy_(self._dX)                                  # the design points themselves
         work[M + N].copy_(self.eng.dev(self.xstar if self.xstar is not None else self.X[0]))
-        found = []
+        # all trials are queued behind each other (the stream orders the re-use of `work`) and read back together: one
+        # synchronisation for the searches, one for the gradient check of the winners
+        queued = []
         for t in range(trials):
             self.eng.shift_points(pool, np.random.uniform(0.0, 1.0, D), out=work[:M])
             # the design points (where f_MAP's maxima sit) and the previous x* join the first trial only: they would
             # claim the same ASCENT_STARTS basins in every trial and leave the uniform candidates' basins unexplored
-            xs, vals = self.eng.mean_search(post, work if t == 0 else work[:M], K=ASCENT_STARTS, sep=5e-2,
-                                            iters=ASCENT_ITERS, tol=1e-9)
-            if len(vals) == 0:
-                continue
-            best = int(np.argmax(vals))
-            # the ascent stops on |projected gradient| * step < 1e-9; the quasi-Newton polish (a device round trip
-            # per function value) is only worth its milliseconds when the winner is NOT yet stationary
-            _, gb = self.eng.mean_grad(post, xs[best][None, :])
-            gb = gb.cpu().numpy()[0]
-            pg = np.where(((xs[best] <= 0.0) & (gb < 0.0)) | ((xs[best] >= 1.0) & (gb > 0.0)), 0.0, gb)
-            if np.abs(pg).max() > POLISH_GRAD_TOL * max(abs(vals[best]), 1e-300):
-                xp, vp = self._polish(xs[best])
-                if vp >= vals[best]:
-                    xs[best], vals[best] = xp, vp
-            found.extend(zip(vals.tolist(), xs))
+            queued.append(self.eng.mean_search(post, work if t == 0 else work[:M], K=ASCENT_STARTS, sep=5e-2,
+                                               iters=ASCENT_ITERS, tol=1e-9, sync=False))
+        found, winners = [], []
+        if queued:
+            all_x = torch.stack([q[0] for q in queued]).cpu().numpy()            # [trials, K, D]
+            all_v = torch.stack([q[1] for q in queued]).cpu().numpy()            # [trials, K], -inf = no start
+            per_trial = []
+            for t in range(trials):
+                ok = np.isfinite(all_v[t])
+                xs, vals = all_x[t][ok], all_v[t][ok]
+                per_trial.append((xs, vals))
+                if len(vals):
+                    winners.append((t, int(np.argmax(vals))))
+            if winners:
+                # the ascent stops on |projected gradient| * step < 1e-9; the quasi-Newton polish (a device round
+                # trip per function value) is only worth its milliseconds when a winner is NOT yet stationary
+                wx = np.stack([per_trial[t][0][b] for t, b in winners])
+                _, gw = self.eng.mean_grad(post, wx)
+                gw = gw.cpu().numpy()
+                for (t, b), gb in zip(winners, gw):
+                    xs, vals = per_trial[t]
+                    pg = np.where(((xs[b] <= 0.0) & (gb < 0.0)) | ((xs[b] >= 1.0) & (gb > 0.0)), 0.0, gb)
+                    if np.abs(pg).max() > POLISH_GRAD_TOL * max(abs(vals[b]), 1e-300):
+                        xp, vp = self._polish(xs[b])
+                        if vp >= vals[b]:
+                            xs[b], vals[b] = xp, vp
+            for xs, vals in per_trial:
+                found.extend(zip(vals.tolist(), xs))
         if not found:                 # no finite mean anywhere (cannot happen with a fitted model): keep the old x*
             x0 = self.xstar if self.xstar is not None else self.X[0]
             return np.asarray(x0, dtype=float).reshape(D,), self.mu_pred(x0), np.asarray(x0, dtype=float).reshape(1, D)
