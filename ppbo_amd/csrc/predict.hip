@@ -350,16 +350,18 @@ __global__ __launch_bounds__(256) void line_mc_kernel(const double* __restrict__
   }
   for (int g = threadIdx.x; g < G16; g += blockDim.x) mus[g] = (g < G) ? m[g] : -INFINITY;
   __syncthreads();
+  // right-looking Cholesky in LDS, two barriers per column: scale the column below the diagonal, then the 16 x 16
+  // thread grid sweeps the trailing lower triangle (no integer division per element)
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   for (int j = 0; j < G; ++j) {
     const double d = Lm[j * ld + j];
     const double piv = (d > 0.0) ? sqrt(d) : 0.0;     // semi-definite: drop the direction
+    for (int i = j + 1 + threadIdx.x; i < G; i += blockDim.x) Lm[i * ld + j] = (piv > 0.0) ? Lm[i * ld + j] / piv : 0.0;
     __syncthreads();
-    for (int i = j + threadIdx.x; i < G; i += blockDim.x)
-      Lm[i * ld + j] = (i == j) ? piv : ((piv > 0.0) ? Lm[i * ld + j] / piv : 0.0);
-    __syncthreads();
-    for (int e = threadIdx.x; e < (G - j - 1) * (G - j - 1); e += blockDim.x) {
-      const int a = j + 1 + e / (G - j - 1), b = j + 1 + e % (G - j - 1);
-      if (b <= a) Lm[a * ld + b] -= Lm[a * ld + j] * Lm[b * ld + j];
+    if (threadIdx.x == 0) Lm[j * ld + j] = piv;        // nobody reads the diagonal entry below
+    for (int a = j + 1 + ty; a < G; a += 16) {
+      const double la = Lm[a * ld + j];
+      for (int b = j + 1 + tx; b <= a; b += 16) Lm[a * ld + b] -= la * Lm[b * ld + j];
     }
     __syncthreads();
   }
