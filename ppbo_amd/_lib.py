@@ -77,6 +77,7 @@ SIGNATURES = {
     "ppbo_rff_score": [_vp, _vp, _i64, _i, _vp, _i, _vp, _d, _vp, _vp, C.POINTER(_d), C.POINTER(_i64), _vp],
     "ppbo_rff_search": [_vp, _vp, _i64, _i, _vp, _i, _vp, _d, _vp, _i, _d, _i, _d, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_rff_terms": [_vp, _vp, _i, _i, _i, _d, _vp, C.POINTER(_d), _vp, _vp, _vp],
+    "ppbo_rff_omega_map": [_vp, _vp, _i, _i, _i, _d, _vp, _i, _d, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i), _vp],
     "ppbo_lu_slogdet": [_vp, _vp, _i, _i, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i), _vp],
     "ppbo_laplace_logdet": [_vp, _vp, _vp, _vp, _i, _i, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i), _vp],
     "ppbo_dgemv": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],

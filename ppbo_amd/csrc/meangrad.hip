@@ -9,6 +9,7 @@
 // registers, accumulate mu and D gradient components, then a shuffle + LDS reduction.  M is small here
 // (a few hundred ascent iterates), so the work per launch is M * N * D * ~6 flops -- microseconds.
 #include "common.h"
+#include "rffmath.h"
 
 namespace {
 
@@ -178,7 +179,10 @@ static inline int select_capacity(int D) {
 }
 
 // mu and its gradient at the point held in LDS (sx), partial sums of this thread's rows reduced into red[wave][.]
-template <int KID, int DP>
+// TR: X is given TRANSPOSED ([D][N]): the threads of a wavefront then read consecutive addresses per coordinate.  With
+// row-major X every lane reads its own row (a 8 D-byte segment each, 64 cache lines per load instruction) and the
+// ascent is bound by the L1's transaction rate, not by arithmetic or latency.
+template <int KID, int DP, int NT = 256, bool TR = false>
 __device__ __forceinline__ void eval_mean_grad(const double* __restrict__ X, int N, int D, const KernParams& p,
                                                const double* __restrict__ alpha, const double* sx,
                                                double (*red)[DP + 1]) {
@@ -186,12 +190,13 @@ __device__ __forceinline__ void eval_mean_grad(const double* __restrict__ X, int
 #pragma unroll
   for (int d = 0; d < DP; ++d) { xc[d] = sx[d]; g[d] = 0.0; }
   double m = 0.0;
-  for (int i = threadIdx.x; i < N; i += 256) {
-    const double* __restrict__ xi = X + (size_t)i * D;
+  for (int i = threadIdx.x; i < N; i += NT) {
+    const double* __restrict__ xi = TR ? X + i : X + (size_t)i * D;
+    const size_t xs = TR ? (size_t)N : 1;
     double dx[DP], s = 0.0;
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
-      dx[d] = (d < D) ? xc[d] - xi[d] : 0.0;
+      dx[d] = (d < D) ? xc[d] - xi[d * xs] : 0.0;
       s += kern_term<KID>(dx[d], d, p);
     }
     const double w = alpha[i] * kern_finish<KID>(s, p);
@@ -209,9 +214,9 @@ __device__ __forceinline__ void eval_mean_grad(const double* __restrict__ X, int
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  m = wave_sum(m);
+  m = wave_sum_dpp(m);                       // DPP: DP + 1 reductions through ds_bpermute would queue on the LDS pipe
 #pragma unroll
-  for (int d = 0; d < DP; ++d) g[d] = wave_sum(g[d]);
+  for (int d = 0; d < DP; ++d) g[d] = wave_sum_dpp(g[d]);
   if (lane == 0) {
     red[wave][DP] = m;
 #pragma unroll
@@ -220,31 +225,38 @@ __device__ __forceinline__ void eval_mean_grad(const double* __restrict__ X, int
 }
 
 // the objective of an ascent: fills red[wave][0..DP) with the gradient's and red[wave][DP] with the value's partial sums
-template <int KID, int DP>
+template <int KID, int DP, int NT>
 struct MeanEval {
   const double* X; int N, D; KernParams p; const double* alpha;
   __device__ __forceinline__ void operator()(const double* sx, double (*red)[DP + 1]) const {
-    eval_mean_grad<KID, DP>(X, N, D, p, alpha, sx, red);
+    eval_mean_grad<KID, DP, NT, true>(X, N, D, p, alpha, sx, red);       // X: the transposed design [D][N]
   }
 };
 
 // one posterior sample of the utility in weight space (random_fourier_sampler.py:45-53,166):
 //   f(x) = a sum_f omega_f cos(w_f.x + b_f),   grad f = -a sum_f omega_f sin(w_f.x + b_f) w_f,   a = sqrt(2 sf^2 / F)
-template <int DP>
+template <int DP, int NT>
 struct RffEval {
-  const double* W; int F, D; const double* b; const double* omega; double amp;
+  const double* W; int F, D; const double* b; const double* omega; double amp; RffPoly P;   // P: unit amplitude
   __device__ __forceinline__ void operator()(const double* sx, double (*red)[DP + 1]) const {
     double xc[DP], g[DP];
 #pragma unroll
     for (int d = 0; d < DP; ++d) { xc[d] = sx[d]; g[d] = 0.0; }
     double m = 0.0;
-    for (int f = threadIdx.x; f < F; f += 256) {
-      const double* __restrict__ wf = W + (size_t)f * D;
+    for (int f = threadIdx.x; f < F; f += NT) {
+      const double* __restrict__ wf = W + f;                 // W: the transposed basis [D][F] (coalesced per coordinate)
       double wv[DP], ph = b[f];
 #pragma unroll
-      for (int d = 0; d < DP; ++d) { wv[d] = (d < D) ? wf[d] : 0.0; ph = fma(wv[d], xc[d], ph); }
+      for (int d = 0; d < DP; ++d) { wv[d] = (d < D) ? wf[(size_t)d * F] : 0.0; ph = fma(wv[d], xc[d], ph); }
+      // cos and sin = cos(. - pi/2) by the branch-free polynomial of the RFF kernels (2 x 20 instructions against a
+      // library sincos with its own range reduction); phases beyond its range take the library path
       double sn, cs;
-      sincos(ph, &sn, &cs);
+      if (fabs(ph) < 0.5 * RFF_COS_FAST_RANGE) {
+        cs = rff_cos_fast(ph, P);
+        sn = rff_cos_fast(ph - 1.57079632679489661923, P);
+      } else {
+        sincos(ph, &sn, &cs);
+      }
       const double om = amp * omega[f];
       m = fma(om, cs, m);
       const double c = -om * sn;
@@ -252,9 +264,9 @@ struct RffEval {
       for (int d = 0; d < DP; ++d) g[d] = fma(c, wv[d], g[d]);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    m = wave_sum(m);
+    m = wave_sum_dpp(m);
 #pragma unroll
-    for (int d = 0; d < DP; ++d) g[d] = wave_sum(g[d]);
+    for (int d = 0; d < DP; ++d) g[d] = wave_sum_dpp(g[d]);
     if (lane == 0) {
       red[wave][DP] = m;
 #pragma unroll
@@ -263,13 +275,23 @@ struct RffEval {
   }
 };
 
-template <int DP, class EVAL>
-__global__ __launch_bounds__(256) void bb_ascent_kernel(EVAL ev, int D, const double* __restrict__ starts,
+// fixed-order sum of the NW wave records of column c
+template <int NW, int DP>
+__device__ __forceinline__ double red_col(const double (*red)[DP + 1], int c) {
+  double t = red[0][c];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) t += red[w][c];
+  return t;
+}
+
+template <int DP, class EVAL, int NT>
+__global__ __launch_bounds__(NT) void bb_ascent_kernel(EVAL ev, int D, const double* __restrict__ starts,
                                                         const int* __restrict__ count, int iters, double tol,
                                                         double* __restrict__ x_out, double* __restrict__ mu_out,
                                                         int* __restrict__ it_out) {
   static_assert(DP <= 64, "lane = coordinate");
-  __shared__ double red[4][DP + 1];
+  constexpr int NW = NT / 64;
+  __shared__ double red[NW][DP + 1];
   __shared__ double sx[DP];
   __shared__ int done;
   const int c = blockIdx.x, tid = threadIdx.x;
@@ -291,16 +313,16 @@ __global__ __launch_bounds__(256) void bb_ascent_kernel(EVAL ev, int D, const do
   __syncthreads();
   if (w0) {
     const int dd = d < DP ? d : DP - 1;
-    g = live ? (red[0][dd] + red[1][dd]) + (red[2][dd] + red[3][dd]) : 0.0;
-    mu = (red[0][DP] + red[1][DP]) + (red[2][DP] + red[3][DP]);
-    const double gn = sqrt(wave_sum(g * g));
+    g = live ? red_col<NW, DP>(red, dd) : 0.0;
+    mu = red_col<NW, DP>(red, DP);
+    const double gn = sqrt(wave_sum_dpp(g * g));
     step = 0.02 / fmax(gn, 1e-300);        // first move: 0.02 in the unit box
   }
   int it = 0;
   for (; it < iters; ++it) {
     if (w0) {
       const double pg = ((x <= 0.0 && g < 0.0) || (x >= 1.0 && g > 0.0)) ? 0.0 : g;
-      const double pn = sqrt(wave_sum(pg * pg));
+      const double pn = sqrt(wave_sum_dpp(pg * pg));
       if (!(pn * step >= tol)) { if (tid == 0) done = 1; }
       else {
         xn = fmin(fmax(x + step * pg, 0.0), 1.0);
@@ -313,12 +335,12 @@ __global__ __launch_bounds__(256) void bb_ascent_kernel(EVAL ev, int D, const do
     __syncthreads();
     if (w0) {
       const int dd = d < DP ? d : DP - 1;
-      const double gnew = live ? (red[0][dd] + red[1][dd]) + (red[2][dd] + red[3][dd]) : 0.0;
-      const double mun = (red[0][DP] + red[1][DP]) + (red[2][DP] + red[3][DP]);
+      const double gnew = live ? red_col<NW, DP>(red, dd) : 0.0;
+      const double mun = red_col<NW, DP>(red, DP);
       const bool ok = mun >= mu;
       const double sv = live ? xn - x : 0.0, yv = gnew - g;
-      const double curv = -wave_sum(sv * yv);          // > 0 where mu is locally concave along the move
-      const double ss = wave_sum(sv * sv);
+      const double curv = -wave_sum_dpp(sv * yv);          // > 0 where mu is locally concave along the move
+      const double ss = wave_sum_dpp(sv * sv);
       step = ok ? (curv > 0.0 ? ss / fmax(curv, 1e-300) : 2.0 * step) : 0.25 * step;
       if (ok) { x = xn; g = gnew; mu = mun; }
     }
@@ -338,32 +360,52 @@ __global__ __launch_bounds__(256) void shift_points_kernel(const double* __restr
   out[i] = v - floor(v);
 }
 
-template <int KID>
-void launch_mean_ascent(const ppbo_model* m, const KernParams& p, const double* starts, const int* count, int K,
-                        int iters, double tol, double* x_out, double* mu_out, int* it_out, hipStream_t s) {
-#define MA_LAUNCH(DP)                                                                                                 \
-  do {                                                                                                                \
-    MeanEval<KID, DP> ev{m->d_X, m->N, m->D, p, m->d_alpha};                                                        \
-    bb_ascent_kernel<DP, MeanEval<KID, DP>><<<K, 256, 0, s>>>(ev, m->D, starts, count, iters, tol, x_out, mu_out, it_out); \
-  } while (0)
-  if (KID == PPBO_KERNEL_CAMPHOR || m->D <= 8) MA_LAUNCH(8);
-  else if (m->D <= 24) MA_LAUNCH(24);
-  else MA_LAUNCH(64);
-#undef MA_LAUNCH
+// out[d][r] = in[r][d]  (R x D row-major -> D x R): the ascent kernels read their operand transposed
+__global__ __launch_bounds__(256) void transpose_rows_kernel(const double* __restrict__ in, int R, int D,
+                                                             double* __restrict__ out) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  for (int d = 0; d < D; ++d) out[(size_t)d * R + r] = in[(size_t)r * D + d];
 }
 
-void launch_rff_ascent(const double* W, int F, int D, const double* b, const double* omega, double amp,
-                       const double* starts, const int* count, int K, int iters, double tol, double* x_out,
-                       double* v_out, hipStream_t s) {
-#define RA_LAUNCH(DP)                                                                                          \
-  do {                                                                                                         \
-    RffEval<DP> ev{W, F, D, b, omega, amp};                                                                    \
-    bb_ascent_kernel<DP, RffEval<DP>><<<K, 256, 0, s>>>(ev, D, starts, count, iters, tol, x_out, v_out, nullptr); \
+template <int KID>
+int launch_mean_ascent(ppbo_ctx* ctx, const ppbo_model* m, const KernParams& p, const double* starts, const int* count, int K,
+                       int iters, double tol, double* x_out, double* mu_out, int* it_out, hipStream_t s) {
+  double* Xt = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_TRANSPOSE, (size_t)m->N * m->D * sizeof(double));
+  if (!Xt) return (int)hipErrorOutOfMemory;
+  transpose_rows_kernel<<<(m->N + 255) / 256, 256, 0, s>>>(m->d_X, m->N, m->D, Xt);
+  // threads per start: one wavefront per SIMD (256 threads) leaves every dependent fp64 instruction's latency exposed;
+  // more wavefronts hide it, as far as the registers of the dimension bucket allow (and the design has rows for them)
+#define MA_LAUNCH(DP, NT)                                                                                             \
+  do {                                                                                                                \
+    MeanEval<KID, DP, NT> ev{Xt, m->N, m->D, p, m->d_alpha};                                                        \
+    bb_ascent_kernel<DP, MeanEval<KID, DP, NT>, NT><<<K, NT, 0, s>>>(ev, m->D, starts, count, iters, tol, x_out, mu_out, it_out); \
   } while (0)
-  if (D <= 8) RA_LAUNCH(8);
-  else if (D <= 24) RA_LAUNCH(24);
-  else RA_LAUNCH(64);
+  const bool tall = m->N >= 1024;
+  if (KID == PPBO_KERNEL_CAMPHOR || m->D <= 8) { if (tall) MA_LAUNCH(8, 1024); else MA_LAUNCH(8, 256); }
+  else if (m->D <= 24) { if (tall) MA_LAUNCH(24, 512); else MA_LAUNCH(24, 256); }
+  else MA_LAUNCH(64, 256);
+#undef MA_LAUNCH
+  return 0;
+}
+
+int launch_rff_ascent(ppbo_ctx* ctx, const double* W_rows, int F, int D, const double* b, const double* omega, double amp,
+                      const double* starts, const int* count, int K, int iters, double tol, double* x_out,
+                      double* v_out, hipStream_t s) {
+  double* W = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_TRANSPOSE, (size_t)F * D * sizeof(double));
+  if (!W) return (int)hipErrorOutOfMemory;
+  transpose_rows_kernel<<<(F + 255) / 256, 256, 0, s>>>(W_rows, F, D, W);
+#define RA_LAUNCH(DP, NT)                                                                                      \
+  do {                                                                                                         \
+    RffEval<DP, NT> ev{W, F, D, b, omega, amp, make_rff_poly(1.0)};                                            \
+    bb_ascent_kernel<DP, RffEval<DP, NT>, NT><<<K, NT, 0, s>>>(ev, D, starts, count, iters, tol, x_out, v_out, nullptr); \
+  } while (0)
+  const bool wide = F >= 1024;
+  if (D <= 8) { if (wide) RA_LAUNCH(8, 1024); else RA_LAUNCH(8, 256); }
+  else if (D <= 24) { if (wide) RA_LAUNCH(24, 512); else RA_LAUNCH(24, 256); }
+  else RA_LAUNCH(64, 256);
 #undef RA_LAUNCH
+  return 0;
 }
 
 template <int KID>
@@ -426,11 +468,13 @@ extern "C" int ppbo_mean_ascent(ppbo_ctx* ctx, const ppbo_model* m, const double
   PPBO_REQUIRE(ctx, d_starts && d_x && d_mu && K > 0 && K <= 65536 && iters >= 0 && tol >= 0, "starts / outputs");
   hipStream_t s = (hipStream_t)stream;
   const KernParams p = make_kern_params(m->kernel_id, m->theta);
+  int rc = 0;
   switch (m->kernel_id) {
-    case PPBO_KERNEL_SE: launch_mean_ascent<PPBO_KERNEL_SE>(m, p, d_starts, nullptr, K, iters, tol, d_x, d_mu, d_iters, s); break;
-    case PPBO_KERNEL_RQ: launch_mean_ascent<PPBO_KERNEL_RQ>(m, p, d_starts, nullptr, K, iters, tol, d_x, d_mu, d_iters, s); break;
-    default: launch_mean_ascent<PPBO_KERNEL_CAMPHOR>(m, p, d_starts, nullptr, K, iters, tol, d_x, d_mu, d_iters, s); break;
+    case PPBO_KERNEL_SE: rc = launch_mean_ascent<PPBO_KERNEL_SE>(ctx, m, p, d_starts, nullptr, K, iters, tol, d_x, d_mu, d_iters, s); break;
+    case PPBO_KERNEL_RQ: rc = launch_mean_ascent<PPBO_KERNEL_RQ>(ctx, m, p, d_starts, nullptr, K, iters, tol, d_x, d_mu, d_iters, s); break;
+    default: rc = launch_mean_ascent<PPBO_KERNEL_CAMPHOR>(ctx, m, p, d_starts, nullptr, K, iters, tol, d_x, d_mu, d_iters, s); break;
   }
+  if (rc) return rc;
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
@@ -469,9 +513,9 @@ extern "C" int ppbo_mean_search(ppbo_ctx* ctx, const ppbo_model* m, const double
   }
   const KernParams p = make_kern_params(m->kernel_id, m->theta);
   switch (m->kernel_id) {
-    case PPBO_KERNEL_SE: launch_mean_ascent<PPBO_KERNEL_SE>(m, p, starts, count, K, iters, tol, d_x, d_mu, nullptr, s); break;
-    case PPBO_KERNEL_RQ: launch_mean_ascent<PPBO_KERNEL_RQ>(m, p, starts, count, K, iters, tol, d_x, d_mu, nullptr, s); break;
-    default: launch_mean_ascent<PPBO_KERNEL_CAMPHOR>(m, p, starts, count, K, iters, tol, d_x, d_mu, nullptr, s); break;
+    case PPBO_KERNEL_SE: if (int rc = launch_mean_ascent<PPBO_KERNEL_SE>(ctx, m, p, starts, count, K, iters, tol, d_x, d_mu, nullptr, s)) return rc; break;
+    case PPBO_KERNEL_RQ: if (int rc = launch_mean_ascent<PPBO_KERNEL_RQ>(ctx, m, p, starts, count, K, iters, tol, d_x, d_mu, nullptr, s)) return rc; break;
+    default: if (int rc = launch_mean_ascent<PPBO_KERNEL_CAMPHOR>(ctx, m, p, starts, count, K, iters, tol, d_x, d_mu, nullptr, s)) return rc; break;
   }
   PPBO_LAUNCH_CHECK(ctx);
   if (h_found) {
@@ -507,8 +551,9 @@ extern "C" int ppbo_rff_search(ppbo_ctx* ctx, const double* d_cand, int64_t M, i
     if (sel_lds > 64 * 1024) ppbo_lds_limit(ctx, (const void*)select_starts_kernel, 150 * 1024);
     select_starts_kernel<<<1, 1024, sel_lds, s>>>(gval, gidx, T, d_cand, D, K, sep * sep, starts, count);
   }
-  launch_rff_ascent(d_W, F, D, d_b, d_omega, std::sqrt(2.0 * sigma_f * sigma_f / (double)F), starts, count, K, iters, tol,
-                    d_x, d_val, s);
+  if (int rc = launch_rff_ascent(ctx, d_W, F, D, d_b, d_omega, std::sqrt(2.0 * sigma_f * sigma_f / (double)F), starts, count, K,
+                                 iters, tol, d_x, d_val, s))
+    return rc;
   PPBO_LAUNCH_CHECK(ctx);
   if (h_found) {
     PPBO_HIP_CHECK(ctx, hipMemcpyAsync(h_found, count, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -10,6 +10,7 @@
 //   rff_terms  : f = Phi^T omega (split GEMV), per-query likelihood weights (one wavefront per
 //                query), then one wavefront per feature row for S_grad / diag(S_hessian).
 #include "linalg.h"
+#include "rffmath.h"
 #include "score.h"
 
 namespace {
@@ -23,52 +24,6 @@ constexpr double INV_SQRT_4PI = 0.28209479177387814347;
     const int gr = r0 + r;
     dstT[d * TS + r] = (gr < n) ? X[(size_t)gr * D + d] : 0.0;
   }
-}
-
-// cos(x) for |x| < 1.6e6 as (-1)^k sin(r), |x| = (2k - 1) pi/2 + r with |r| <= pi/2, k = rint(|x|/pi + 1/2):
-// Cody-Waite reduction by three 33-bit pieces of pi/2 (the odd multiplier 2k-1 < 2^21 is exact against each), then
-// ONE odd minimax polynomial sin(r) = r P(r^2), nine coefficients (fit error 2e-19, <= 1 ulp in double; the recipe
-// is tools/expfit.py sin_fit) -- 17 fp64 instructions + 3 integer ones for the sign (the parity of k moved into
-// the sign bit), against ~40 for a library cosine that reduces to pi/4 and evaluates a sine AND a cosine kernel.
-// The RFF phases w.x + b are O(sqrt(D)/l) (tens), far inside the fast range; larger arguments take the library
-// path behind a wave-uniform branch (rff_cos_slow is out of line: one copy per kernel, not one per element).
-constexpr double RFF_COS_FAST_RANGE = 1.6e6;
-__device__ __attribute__((noinline)) double rff_cos_slow(double x) { return cos(x); }
-
-struct RffPoly {   // c[k] = amplitude * (coefficient of r^(2k+1)), prepared on the host: the feature scale rides along
-  double c[9];
-};
-static inline RffPoly make_rff_poly(double amplitude) {
-  static const double s[9] = {0x1.0000000000000p+0,  -0x1.5555555555555p-3, 0x1.11111111110bcp-7,
-                              -0x1.a01a01a0147d9p-13, 0x1.71de3a528c5e5p-19, -0x1.ae6454d01e7a1p-26,
-                              0x1.6123ccc2fc0b0p-33,  -0x1.ae4398eddfa1fp-41, 0x1.8837bd66b70acp-49};
-  RffPoly p;
-  for (int k = 0; k < 9; ++k) p.c[k] = amplitude * s[k];
-  return p;
-}
-
-// amplitude * cos(x); branch-free, valid for |x| < RFF_COS_FAST_RANGE: independent evaluations interleave
-__device__ __forceinline__ double rff_cos_fast(double x, const RffPoly& P) {
-  const double ax = fabs(x);
-  const double kf = rint(fma(ax, 3.18309886183790671538e-01, 0.5));
-  const double n = fma(2.0, kf, -1.0);
-  double r = fma(-n, 1.57079632673412561417e+00, ax);
-  r = fma(-n, 6.07710050630396597660e-11, r);
-  r = fma(-n, 2.02226624871116645580e-21, r);
-  const double z = r * r;
-  double q = P.c[8];
-  q = fma(q, z, P.c[7]);
-  q = fma(q, z, P.c[6]);
-  q = fma(q, z, P.c[5]);
-  q = fma(q, z, P.c[4]);
-  q = fma(q, z, P.c[3]);
-  q = fma(q, z, P.c[2]);
-  q = fma(q, z, P.c[1]);
-  q = fma(q, z, P.c[0]);
-  const double sn = r * q;
-  // (-1)^k: the parity of k goes straight into the sign bit
-  const int flip = ((int)kf) << 31;
-  return __hiloint2double(__double2hiint(sn) ^ flip, __double2loint(sn));
 }
 
 __device__ __forceinline__ double rff_cos(double x, const RffPoly& P) {
@@ -402,6 +357,78 @@ __global__ __launch_bounds__(1024) void rff_S_kernel(const double* __restrict__ 
   }
 }
 
+// One safeguarded Newton step of update_omega_MAP (random_fourier_sampler.py:124-132; the Hessian of S is diagonal):
+// step = g / max(-h, 1e-12) cut back to the trust radius, trial = omega + step, and the scalars the accept / reject
+// rule needs -- out[0] = |uncut step|, out[1] = predicted gain g.step - 1/2 step.(curv step), out[2] = |g|.
+__global__ __launch_bounds__(1024) void rff_newton_step_kernel(const double* __restrict__ omega, const double* __restrict__ g,
+                                                               const double* __restrict__ h, int F, double radius,
+                                                               double* __restrict__ trial, double* __restrict__ out) {
+  __shared__ double sh[3][16];
+  __shared__ double s_scale;
+  const int t = threadIdx.x;
+  double n2 = 0.0, g2 = 0.0;
+  for (int f = t; f < F; f += 1024) {
+    const double curv = fmax(-h[f], 1e-12);
+    const double st = g[f] / curv;
+    n2 += st * st;
+    g2 += g[f] * g[f];
+  }
+  n2 = wave_sum(n2);
+  g2 = wave_sum(g2);
+  if ((t & 63) == 0) { sh[0][t >> 6] = n2; sh[1][t >> 6] = g2; }
+  __syncthreads();
+  if (t == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 16; ++w) { a += sh[0][w]; b += sh[1][w]; }
+    const double nrm = sqrt(a);
+    out[0] = nrm;
+    out[2] = sqrt(b);
+    s_scale = (nrm > radius) ? radius / nrm : 1.0;
+  }
+  __syncthreads();
+  const double scale = s_scale;
+  double pred = 0.0;
+  for (int f = t; f < F; f += 1024) {
+    const double curv = fmax(-h[f], 1e-12);
+    const double st = scale * (g[f] / curv);
+    trial[f] = omega[f] + st;
+    pred += g[f] * st - 0.5 * st * (curv * st);
+  }
+  pred = wave_sum(pred);
+  if ((t & 63) == 0) sh[2][t >> 6] = pred;
+  __syncthreads();
+  if (t == 0) {
+    double a = 0.0;
+    for (int w = 0; w < 16; ++w) a += sh[2][w];
+    out[1] = a;
+  }
+}
+
+// S (optional, into *d_S_out[0]), grad S and diag(S_hessian) at omega, enqueued only
+int rff_terms_async(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, double sigma, const double* d_omega,
+                    bool want_S, double* d_grad, double* d_hdiag, double** d_S_out, hipStream_t s) {
+  const int mblk = m + 1, n_q = N / mblk;
+  const int n_split = 32;
+  const int f_per_split = (F + n_split - 1) / n_split;
+  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, ((size_t)(n_split + 3) * N + n_q + 8) * sizeof(double));
+  if (!ws) return (int)hipErrorOutOfMemory;
+  double* part = ws;
+  double* f = ws + (size_t)n_split * N;
+  double* a = f + N;
+  double* h = a + N;
+  double* tq = h + N;
+  double* sc = tq + n_q;
+  phiT_omega_kernel<<<dim3((N + 255) / 256, n_split), 256, 0, s>>>(d_Phi, F, N, d_omega, f_per_split, part);
+  sum_parts_kernel<<<(N + 255) / 256, 256, 0, s>>>(part, n_split, N, f);
+  rff_weights_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(f, N, mblk, n_q, sigma, tq, a, h);
+  if (d_grad || d_hdiag)
+    rff_rows_kernel<<<(F + 3) / 4, 256, 0, s>>>(d_Phi, F, N, mblk, d_omega, a, h, d_grad, d_hdiag);
+  if (want_S) rff_S_kernel<<<1, 1024, 0, s>>>(d_omega, F, tq, n_q, m, sc);
+  PPBO_LAUNCH_CHECK(ctx);
+  if (d_S_out) *d_S_out = sc;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -529,29 +556,59 @@ int ppbo_rff_terms(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, doub
   PPBO_REQUIRE(ctx, d_Phi && d_omega, "null pointer");
   PPBO_REQUIRE(ctx, F > 0 && N > 0 && m >= 1 && sigma > 0 && N % (m + 1) == 0, "sizes");
   hipStream_t s = (hipStream_t)stream;
-  const int mblk = m + 1, n_q = N / mblk;
-  const int n_split = 32;
-  const int f_per_split = (F + n_split - 1) / n_split;
-  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, ((size_t)(n_split + 3) * N + n_q + 8) * sizeof(double));
-  if (!ws) return (int)hipErrorOutOfMemory;
-  double* part = ws;
-  double* f = ws + (size_t)n_split * N;
-  double* a = f + N;
-  double* h = a + N;
-  double* tq = h + N;
-  double* sc = tq + n_q;
-  phiT_omega_kernel<<<dim3((N + 255) / 256, n_split), 256, 0, s>>>(d_Phi, F, N, d_omega, f_per_split, part);
-  sum_parts_kernel<<<(N + 255) / 256, 256, 0, s>>>(part, n_split, N, f);
-  rff_weights_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(f, N, mblk, n_q, sigma, tq, a, h);
-  if (d_grad || d_hdiag)
-    rff_rows_kernel<<<(F + 3) / 4, 256, 0, s>>>(d_Phi, F, N, mblk, d_omega, a, h, d_grad, d_hdiag);
-  PPBO_LAUNCH_CHECK(ctx);
+  double* sc = nullptr;
+  if (int rc = rff_terms_async(ctx, d_Phi, F, N, m, sigma, d_omega, h_S != nullptr, d_grad, d_hdiag, &sc, s)) return rc;
   if (h_S) {
-    rff_S_kernel<<<1, 1024, 0, s>>>(d_omega, F, tq, n_q, m, sc);
-    PPBO_LAUNCH_CHECK(ctx);
     PPBO_HIP_CHECK(ctx, hipMemcpyAsync(h_S, sc, sizeof(double), hipMemcpyDeviceToHost, s));
     PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
   }
+  return 0;
+}
+
+int ppbo_rff_omega_map(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, double sigma, double* d_omega,
+                       int maxiter, double gtol, double* h_S, double* h_gradnorm, int* h_iterations, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_Phi && d_omega, "null pointer");
+  PPBO_REQUIRE(ctx, F > 0 && N > 0 && m >= 1 && sigma > 0 && N % (m + 1) == 0 && maxiter >= 0 && gtol >= 0, "sizes");
+  hipStream_t s = (hipStream_t)stream;
+  // omega / gradient / Hessian diagonal of the accepted point and of the trial point, 4 scalars, pinned read-back
+  double* buf = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH_SMALL, ((size_t)6 * F + 8) * sizeof(double));
+  double* host = (double*)ppbo_pinned(ctx, (64 + 8) * sizeof(double));
+  if (!buf || !host) return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "omega_MAP workspace");
+  host += 64;                                    // the first 64 doubles of the pinned block belong to the fit
+  double *om = buf, *g = buf + F, *h = buf + 2 * F, *omt = buf + 3 * F, *gt = buf + 4 * F, *ht = buf + 5 * F;
+  double* out = buf + 6 * F;                     // [0] |unscaled step|, [1] predicted gain, [2] |g|, [3] S(trial)
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(om, d_omega, (size_t)F * sizeof(double), hipMemcpyDeviceToDevice, s));
+  double* sc = nullptr;
+  if (int rc = rff_terms_async(ctx, d_Phi, F, N, m, sigma, om, true, g, h, &sc, s)) return rc;
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(host, sc, sizeof(double), hipMemcpyDeviceToHost, s));
+  PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  double S = host[0], radius = 1.0, gn = INFINITY;
+  int it = 0;
+  for (; it < maxiter; ++it) {
+    // the step from the accepted point and, speculatively, the terms at the trial point: ONE read-back per iteration
+    rff_newton_step_kernel<<<1, 1024, 0, s>>>(om, g, h, F, radius, omt, out);
+    if (int rc = rff_terms_async(ctx, d_Phi, F, N, m, sigma, omt, true, gt, ht, &sc, s)) return rc;
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(out + 3, sc, sizeof(double), hipMemcpyDeviceToDevice, s));
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(host, out, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    const double nrm = host[0], pred = host[1], Sn = host[3];
+    gn = host[2];
+    if (gn < gtol) break;                        // the accepted point is stationary: the trial is not used
+    const double rho = (pred > 0.0) ? (Sn - S) / pred : -1.0;
+    if (rho < 0.25) radius *= 0.25;
+    else if (rho > 0.75 && nrm >= radius) radius = (2.0 * radius < 1000.0) ? 2.0 * radius : 1000.0;
+    if (rho > 0.15) {
+      std::swap(om, omt); std::swap(g, gt); std::swap(h, ht);
+      S = Sn;
+    }
+    if (radius < 1e-14) { ++it; break; }
+  }
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(d_omega, om, (size_t)F * sizeof(double), hipMemcpyDeviceToDevice, s));
+  PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  if (h_S) *h_S = S;
+  if (h_gradnorm) *h_gradnorm = gn;
+  if (h_iterations) *h_iterations = it;
   return 0;
 }
 

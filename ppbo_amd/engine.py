@@ -460,6 +460,17 @@ class Engine:
         self._check(rc, "ppbo_rff_score")
         return sc, bv.value, bi.value
 
+    def rff_omega_map(self, Phi, omega0, m, sigma, maxiter=500, gtol=1e-6):
+        """Device-resident maximiser of S (ppbo_rff_omega_map): returns (omega_MAP as NumPy, S, |grad S|, iterations)."""
+        Phi = self.dev(Phi)
+        om = self.dev(omega0).reshape(-1).clone()
+        F, N = Phi.shape
+        S, gn, it = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+        rc = self.lib.ppbo_rff_omega_map(self.ctx, _ptr(Phi), F, N, int(m), float(sigma), _ptr(om), int(maxiter), float(gtol),
+                                         C.byref(S), C.byref(gn), C.byref(it), self._stream())
+        self._check(rc, "ppbo_rff_omega_map")
+        return om.cpu().numpy(), S.value, gn.value, it.value
+
     def randn(self, seed, *shape):
         """Standard normal draws generated on the device (ppbo_randn): a pure function of (seed, index)."""
         out = self.empty(*shape)

@@ -35,11 +35,10 @@ class Hsampler:
         self.obs_indices = gp_model.obs_indices
         self.kernel = str(gp_model.kernel.__name__)
         self.theta = gp_model.theta
-        self.phi_X = None
+        self._phi_X = None        # host copy of Phi(X), made on first access (67 MB at C3: 5 ms nobody needs per update)
         self.omega_MAP = None
-        self.covariance = None
-        self.covariance_inv = None
-        self.cov_diag = None
+        self.cov_diag = None      # the posterior covariance of omega is diagonal (S_hessian is): this is its diagonal
+        self._hess_diag = None
         self.verbose = False
         self._dPhi = None
 
@@ -67,7 +66,29 @@ class Hsampler:
 
     def update_phi_X(self):
         self._dPhi = self.eng.rff_project(self.X, self.W, self.b.ravel(), self.theta[2])
-        self.phi_X = self._dPhi.cpu().numpy()
+        self._phi_X = None
+
+    @property
+    def phi_X(self):
+        """Phi(X) [F, N] as a NumPy array (random_fourier_sampler.py:57-58); lives on the device, copied on demand."""
+        if self._phi_X is None and self._dPhi is not None:
+            self._phi_X = self._dPhi.cpu().numpy()
+        return self._phi_X
+
+    @phi_X.setter
+    def phi_X(self, value):
+        self._phi_X = None if value is None else np.asarray(value, dtype=float)
+        self._dPhi = None if value is None else self.eng.dev(self._phi_X)
+
+    @property
+    def covariance_inv(self):
+        """-S_hessian(omega_MAP) as the dense F x F matrix the reference stores (:136); built on demand."""
+        return None if self._hess_diag is None else np.diag(self._hess_diag)
+
+    @property
+    def covariance(self):
+        """The dense F x F posterior covariance of the reference (:137); built on demand from its diagonal."""
+        return None if self.cov_diag is None else np.diag(self.cov_diag)
 
     # ---- weight-space Laplace terms ------------------------------------------------
     def _terms(self, omega, theta):
@@ -90,28 +111,10 @@ class Hsampler:
         trust-region Newton of the reference reduces to per-coordinate safeguarded Newton steps."""
         omega = np.random.randn(self.nFeatures)
         start = time.time()
-        S, g, h = self._terms(omega, self.theta)
-        g, h = g.cpu().numpy(), h.cpu().numpy()
-        radius = 1.0
-        for _ in range(500):
-            if np.linalg.norm(g) < 1e-6:
-                break
-            curv = np.maximum(-h, 1e-12)                     # -S is convex where h < 0
-            step = g / curv
-            nrm = np.linalg.norm(step)
-            if nrm > radius:
-                step *= radius / nrm
-            Sn, gn, hn = self._terms(omega + step, self.theta)
-            pred = g @ step - 0.5 * step @ (curv * step)
-            rho = (Sn - S) / pred if pred > 0 else -1.0
-            if rho < 0.25:
-                radius *= 0.25
-            elif rho > 0.75 and nrm >= radius:
-                radius = min(2.0 * radius, 1000.0)
-            if rho > 0.15:
-                omega, S, g, h = omega + step, Sn, gn.cpu().numpy(), hn.cpu().numpy()
-            if radius < 1e-14:
-                break
+        # the whole safeguarded Newton loop runs behind one call (ppbo_rff_omega_map): omega, gradient and Hessian
+        # diagonal stay on the device, four scalars per iteration come back
+        omega, S, gnorm, iters = self.eng.rff_omega_map(self._dPhi, omega, self.m, self.theta[0], maxiter=500, gtol=1e-6)
+        self.omega_MAP_stats = {"S": S, "gradnorm": gnorm, "iterations": iters}
         if self.verbose:
             print("... this took " + str(time.time() - start) + " seconds.")
         self.omega_MAP = omega
@@ -121,10 +124,8 @@ class Hsampler:
         if np.any(hd <= 0):
             print("---!!!--- Posterior covariance matrix is not PSD ---!!!---")
             return
+        self._hess_diag = hd
         self.cov_diag = 1.0 / hd
-        if self.nFeatures <= 4096:                            # dense forms only for attribute compatibility
-            self.covariance_inv = np.diag(hd)
-            self.covariance = np.diag(self.cov_diag)
 
     def sample_omega(self):
         if self.cov_diag is None:
