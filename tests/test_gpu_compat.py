@@ -146,3 +146,20 @@ def test_device_normal_draws(eng):
     with pytest.raises(RuntimeError):
         eng.lib.ppbo_randn.restype  # noqa: B018  (binding exists)
         eng._check(eng.lib.ppbo_randn(eng.ctx, 1, None, 10, eng._stream()), "ppbo_randn")
+
+
+def test_rff_omega_map_entry_point(eng):
+    """ppbo_rff_omega_map on a small random basis: lands on a stationary point of S (|grad S| < gtol, every Hessian
+    diagonal entry negative there: a maximum), a second call from the result is a no-op, bad sizes are refused."""
+    rng = np.random.default_rng(2)
+    m, n_q, F = 5, 9, 70
+    N = n_q * (m + 1)
+    Phi = rng.standard_normal((F, N)) * 0.2
+    om, S, gn, it = eng.rff_omega_map(Phi, rng.standard_normal(F), m, 0.3, maxiter=500, gtol=1e-6)
+    assert gn < 1e-6 and 0 < it < 500
+    S1, g1, h1 = eng.rff_terms(Phi, om, m, 0.3)
+    assert abs(S1 - S) <= 1e-12 * max(1.0, abs(S)) and np.linalg.norm(host(g1)) < 1e-6 and np.all(host(h1) < 0)
+    om2, S2, gn2, it2 = eng.rff_omega_map(Phi, om, m, 0.3, maxiter=500, gtol=1e-6)
+    assert it2 == 0 and np.array_equal(om2, om)
+    with pytest.raises(RuntimeError):
+        eng.rff_omega_map(Phi[:, :-1], rng.standard_normal(F), m, 0.3)
