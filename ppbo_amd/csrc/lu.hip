@@ -116,7 +116,7 @@ __device__ __forceinline__ PivRec wave_piv(PivRec a) {
 
 // One column step of the register-resident panel (J is a template parameter: every index into a[][] is static, or the
 // panel would be demoted to scratch).
-template <int RPT, int J>
+template <int RPT, int NT, int J>
 __device__ __forceinline__ void lu_reg_column(double (&a)[RPT][LNB], int N, int k0, int* __restrict__ ipiv,
                                               int* __restrict__ info, PivRec* sh, double* rowc, double* prow) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -124,7 +124,7 @@ __device__ __forceinline__ void lu_reg_column(double (&a)[RPT][LNB], int N, int 
   PivRec best{0.0, -1};
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int r = k0 + t + 1024 * i;
+    const int r = k0 + t + NT * i;
     if (r >= col && r < N) {
       const double v = fabs(a[i][J]);
       if (best.idx < 0 || v > best.val) { best.val = v; best.idx = r; }   // ascending r: strict > keeps the first
@@ -136,7 +136,7 @@ __device__ __forceinline__ void lu_reg_column(double (&a)[RPT][LNB], int N, int 
   // every wavefront merges the 16 records itself (lane l < 16 takes record l): no serial merge by one thread, no
   // second barrier to publish the winner
   PivRec mine{0.0, -1};
-  if (lane < 16) mine = sh[lane];
+  if (lane < NT / 64) mine = sh[lane];
   const PivRec win = wave_piv(mine);
   if (t == 0) {
     ipiv[col] = win.idx;
@@ -145,7 +145,7 @@ __device__ __forceinline__ void lu_reg_column(double (&a)[RPT][LNB], int N, int 
   const int p = win.idx;
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int r = k0 + t + 1024 * i;
+    const int r = k0 + t + NT * i;
     if (r == col) {
 #pragma unroll
       for (int c = 0; c < LNB; ++c) rowc[c] = a[i][c];
@@ -159,7 +159,7 @@ __device__ __forceinline__ void lu_reg_column(double (&a)[RPT][LNB], int N, int 
   if (p != col) {
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-      const int r = k0 + t + 1024 * i;
+      const int r = k0 + t + NT * i;
       if (r == col) {
 #pragma unroll
         for (int c = 0; c < LNB; ++c) a[i][c] = prow[c];
@@ -171,11 +171,15 @@ __device__ __forceinline__ void lu_reg_column(double (&a)[RPT][LNB], int N, int 
   }
   const double piv = prow[J];
   if (piv != 0.0) {
+    // LAPACK's dgetf2 / dgetrf2 scale the column by the reciprocal of the pivot (for |pivot| >= sfmin), not by a
+    // division per entry; one correctly rounded reciprocal per thread and column instead of RPT divisions
+    const bool tiny = fabs(piv) < 2.2250738585072014e-308;
+    const double rinv = 1.0 / piv;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-      const int r = k0 + t + 1024 * i;
+      const int r = k0 + t + NT * i;
       if (r > col && r < N) {
-        const double l = a[i][J] / piv;
+        const double l = tiny ? a[i][J] / piv : a[i][J] * rinv;
         a[i][J] = l;
 #pragma unroll
         for (int c = J + 1; c < LNB; ++c) a[i][c] -= l * prow[c];
@@ -186,9 +190,10 @@ __device__ __forceinline__ void lu_reg_column(double (&a)[RPT][LNB], int N, int 
   // sh precede it), and rowc / prow only after the next column's first barrier (all reads of them precede that)
 }
 
-// The panel in registers: thread t owns rows k0 + t + 1024 i (i < RPT) of the panel's nb <= 16 columns.
-template <int RPT>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void getrf_panel_reg_kernel(
+// The panel in registers: thread t owns rows k0 + t + NT i (i < RPT) of the panel's nb <= 16 columns; NT shrinks with
+// the number of rows left (fewer wavefronts to issue and to meet at the two barriers of a column).
+template <int RPT, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 256, NT / 256))) void getrf_panel_reg_kernel(
     double* __restrict__ A, int lda, int N, int k0, int nb, int* __restrict__ ipiv, int* __restrict__ info) {
   __shared__ PivRec sh[16];
   __shared__ double rowc[LNB], prow[LNB];    // the row at the diagonal before the swap; the pivot row
@@ -196,18 +201,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   double a[RPT][LNB];
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int r = k0 + t + 1024 * i;
+    const int r = k0 + t + NT * i;
 #pragma unroll
     for (int c = 0; c < LNB; ++c) a[i][c] = (r < N && c < nb) ? A[(size_t)r * lda + k0 + c] : 0.0;
   }
-#define LU_COL(J) if (J < nb) lu_reg_column<RPT, J>(a, N, k0, ipiv, info, sh, rowc, prow);     /* nb is uniform */
+#define LU_COL(J) if (J < nb) lu_reg_column<RPT, NT, J>(a, N, k0, ipiv, info, sh, rowc, prow);     /* nb is uniform */
   LU_COL(0) LU_COL(1) LU_COL(2) LU_COL(3) LU_COL(4) LU_COL(5) LU_COL(6) LU_COL(7)
   LU_COL(8) LU_COL(9) LU_COL(10) LU_COL(11) LU_COL(12) LU_COL(13) LU_COL(14) LU_COL(15)
 #undef LU_COL
   static_assert(LNB == 16, "LU_COL list");
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    const int r = k0 + t + 1024 * i;
+    const int r = k0 + t + NT * i;
     if (r < N) {
 #pragma unroll
       for (int c = 0; c < LNB; ++c)
@@ -317,8 +322,10 @@ int ppbo_lu_slogdet(ppbo_ctx* ctx, double* d_A, int N, int lda, double* h_u_sign
   PPBO_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(int), s));
   for (int k0 = 0; k0 < N; k0 += LNB) {
     const int nb = (N - k0 < LNB) ? (N - k0) : LNB;
-    if (N - k0 <= 1024) getrf_panel_reg_kernel<1><<<1, 1024, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv, d_info);
-    else if (N - k0 <= 2048) getrf_panel_reg_kernel<2><<<1, 1024, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv, d_info);
+    if (N - k0 <= 256) getrf_panel_reg_kernel<1, 256><<<1, 256, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv, d_info);
+    else if (N - k0 <= 512) getrf_panel_reg_kernel<1, 512><<<1, 512, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv, d_info);
+    else if (N - k0 <= 1024) getrf_panel_reg_kernel<1, 1024><<<1, 1024, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv, d_info);
+    else if (N - k0 <= 2048) getrf_panel_reg_kernel<2, 1024><<<1, 1024, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv, d_info);
     else getrf_panel_kernel<<<1, 1024, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv, d_info);
     if (N - nb > 0) laswp_kernel<<<(N - nb + 255) / 256, 256, 0, s>>>(d_A, lda, N, k0, nb, d_ipiv);
     const int rest = N - k0 - nb;
