@@ -157,6 +157,8 @@ __device__ __forceinline__ double dpp_add(double v, const int ctrl_selector) {
   return v + __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double quad_sum_dpp(double v) { return dpp_add(dpp_add(v, 0), 1); }
+// sum over each row of 16 lanes (every lane of the row ends with the row's sum): four DPP steps, no LDS, no readlane
+__device__ __forceinline__ double row16_sum_dpp(double v) { return dpp_add(dpp_add(dpp_add(dpp_add(v, 0), 1), 2), 3); }
 __device__ __forceinline__ double wave_sum_dpp(double v) {
   v = dpp_add(dpp_add(dpp_add(dpp_add(v, 0), 1), 2), 3);
   double r[4];

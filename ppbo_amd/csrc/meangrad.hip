@@ -213,14 +213,17 @@ __device__ __forceinline__ void eval_mean_grad(const double* __restrict__ X, int
       for (int d = 0; d < DP; ++d) g[d] += coef * dx[d];
     }
   }
+  // DPP sums over rows of 16 lanes (DP + 1 reductions through ds_bpermute would queue on the LDS pipe, and finishing
+  // each of them across the four rows costs eight v_readlane more): one record per row, 4 per wavefront
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  m = wave_sum_dpp(m);                       // DPP: DP + 1 reductions through ds_bpermute would queue on the LDS pipe
+  m = row16_sum_dpp(m);
 #pragma unroll
-  for (int d = 0; d < DP; ++d) g[d] = wave_sum_dpp(g[d]);
-  if (lane == 0) {
-    red[wave][DP] = m;
+  for (int d = 0; d < DP; ++d) g[d] = row16_sum_dpp(g[d]);
+  if ((lane & 15) == 0) {
+    double* r = red[4 * wave + (lane >> 4)];
+    r[DP] = m;
 #pragma unroll
-    for (int d = 0; d < DP; ++d) red[wave][d] = g[d];
+    for (int d = 0; d < DP; ++d) r[d] = g[d];
   }
 }
 
@@ -264,18 +267,19 @@ struct RffEval {
       for (int d = 0; d < DP; ++d) g[d] = fma(c, wv[d], g[d]);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    m = wave_sum_dpp(m);
+    m = row16_sum_dpp(m);
 #pragma unroll
-    for (int d = 0; d < DP; ++d) g[d] = wave_sum_dpp(g[d]);
-    if (lane == 0) {
-      red[wave][DP] = m;
+    for (int d = 0; d < DP; ++d) g[d] = row16_sum_dpp(g[d]);
+    if ((lane & 15) == 0) {
+      double* r = red[4 * wave + (lane >> 4)];
+      r[DP] = m;
 #pragma unroll
-      for (int d = 0; d < DP; ++d) red[wave][d] = g[d];
+      for (int d = 0; d < DP; ++d) r[d] = g[d];
     }
   }
 };
 
-// fixed-order sum of the NW wave records of column c
+// fixed-order sum of the NW records of column c
 template <int NW, int DP>
 __device__ __forceinline__ double red_col(const double (*red)[DP + 1], int c) {
   double t = red[0][c];
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(NT) void bb_ascent_kernel(EVAL ev, int D, const dou
                                                         double* __restrict__ x_out, double* __restrict__ mu_out,
                                                         int* __restrict__ it_out) {
   static_assert(DP <= 64, "lane = coordinate");
-  constexpr int NW = NT / 64;
+  constexpr int NW = NT / 16;              // one record per row of 16 lanes
   __shared__ double red[NW][DP + 1];
   __shared__ double sx[DP];
   __shared__ int done;
