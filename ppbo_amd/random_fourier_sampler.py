@@ -157,7 +157,9 @@ class Hsampler:
         work = torch.empty((M + k, D), dtype=torch.float64, device=self.eng.device)
         self.eng.shift_points(pool, np.random.uniform(0, 1, D), out=work[:M])
         work[M:].copy_(self.eng.dev(near))
-        xs, vals = self.eng.rff_search(work, self.W, self.b.ravel(), self.theta[2], omega, K=RFF_STARTS)
+        # 100 Barzilai-Borwein iterations per start: the winning start is stationary after ~50 (tests/probes/
+        # rff_ascent_scale.py: the same maximum at 50, 100 and 200), the cap only bounds the starts that keep bouncing
+        xs, vals = self.eng.rff_search(work, self.W, self.b.ravel(), self.theta[2], omega, K=RFF_STARTS, iters=100)
         if self.verbose:
             print("Optimization of f_approx took " + str(time.time() - start) + " seconds.")
         if len(vals) == 0 or not np.isfinite(vals).any():
