@@ -79,6 +79,39 @@ __global__ __launch_bounds__(256) void fill_gramlike(double* __restrict__ S, int
   }
 }
 
+// 128 x 128 super-tiles of the upper triangle (diagonal included), one workgroup per 32 x 128 strip of a super-tile:
+// the direct strip as full 1 KB rows (64 lanes x 16 B), its mirror image (128 rows x 32 columns) as 256 B row pieces
+// (16 lanes x 16 B, 4 rows per instruction).  WT: write-through stores.
+template <int WT>
+__global__ __launch_bounds__(256) void fill_strips(double* __restrict__ S, int N, int nt, double v) {
+  const int t = blockIdx.x >> 2, strip = blockIdx.x & 3;
+  const double q = 2.0 * nt + 1.0;
+  int bi = (int)floor((q - sqrt(q * q - 8.0 * (double)t)) * 0.5);
+  while (bi > 0 && t < bi * nt - bi * (bi - 1) / 2) --bi;
+  while (t >= (bi + 1) * nt - (bi + 1) * bi / 2) ++bi;
+  const int bj = bi + (t - (bi * nt - bi * (bi - 1) / 2));
+  const int i0 = bi * 128 + 32 * strip, j0 = bj * 128;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    double* p = S + (size_t)(i0 + 8 * w + a) * N + j0 + 2 * lane;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t val = {v, v + a};
+    if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(val) : "memory");
+    else *reinterpret_cast<double2*>(p) = make_double2(v, v + a);
+  }
+  if (bi == bj) return;
+  const int mr = lane >> 4, mc = (lane & 15) * 2;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    double* p = S + (size_t)(j0 + 32 * w + 4 * a + mr) * N + i0 + mc;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t val = {v, v + a};
+    if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(val) : "memory");
+    else *reinterpret_cast<double2*>(p) = make_double2(v, v + a);
+  }
+}
+
 template <typename F>
 static void timeit(const char* tag, double bytes, F launch) {
   hipEvent_t e0, e1;
@@ -125,6 +158,13 @@ int main() {
       timeit(tag, bytes, [&] { fill_gramlike<0><<<nblk, 256>>>(d, N, nt, 1.0); });
       snprintf(tag, sizeof tag, "N=%d gram-like 512B pieces", N);
       timeit(tag, bytes, [&] { fill_gramlike<1><<<nblk, 256>>>(d, N, nt, 1.0); });
+    }
+    {
+      const int nt = N / 128, nblk = nt * (nt + 1) / 2 * 4;
+      snprintf(tag, sizeof tag, "N=%d strips 32x128 + mirror 256B", N);
+      timeit(tag, bytes, [&] { fill_strips<0><<<nblk, 256>>>(d, N, nt, 1.0); });
+      snprintf(tag, sizeof tag, "N=%d strips, write-through", N);
+      timeit(tag, bytes, [&] { fill_strips<1><<<nblk, 256>>>(d, N, nt, 1.0); });
     }
     snprintf(tag, sizeof tag, "N=%d memset", N);
     timeit(tag, bytes, [&] { hipMemsetAsync(d, 0, n * 8, 0); });
