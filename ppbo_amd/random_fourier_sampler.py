@@ -106,6 +106,38 @@ class Hsampler:
     def S_hessian(self, omega, theta):
         return np.diag(self.S_hessian_diag(omega, theta))
 
+    # ---- the reference's per-query helpers of S (random_fourier_sampler.py:62-102), kept for callers that use them;
+    # S / S_grad / S_hessian above do NOT go through them (ppbo_rff_terms sums over all queries in one pass)
+    def sum_Phi(self, i, order_of_derivative, f, sigma, sample_points=None, weights=None):
+        """Query i (an element of obs_indices): order 0 -> sum_j Phi(Delta_j / sqrt 2) (scalar, closed form of the
+        Gauss-Hermite integral); order 1 -> sum_j (phi_X[:, i+1+j] - phi_X[:, i]) var2_normal_pdf(Delta_j) (a vector
+        of nFeatures); order 2 -> sum_j -(phi_X[:, i+1+j] - phi_X[:, i])^2 Delta_j / 2 var2_normal_pdf(Delta_j).  The
+        per-pseudo-observation weights come from ppbo_sum_phi's kernel family (ppbo_laplace_terms), the feature
+        contractions from the device GEMM on the resident Phi(X)."""
+        if order_of_derivative not in (0, 1, 2):
+            print("The derivatives of an order higher than 2 are not needed!")
+            return None
+        i, m = int(i), self.m
+        f = np.asarray(f, dtype=float).ravel()
+        if order_of_derivative == 0:
+            return float(self.eng.sum_phi(f, m, sigma, 0).cpu().numpy()[i // (m + 1)])
+        # beta (order 1) and Lambda's off-diagonal (order 2) carry exactly these weights, up to their scale factors
+        _, beta, _, lo = self.eng.laplace_terms(f, m, sigma)
+        blk = slice(i + 1, i + m + 1)
+        if order_of_derivative == 1:
+            w = -(beta[blk] * (sigma * m))                    # var2_normal_pdf(Delta_j)
+        else:
+            w = lo[blk] * (m * sigma ** 2)                    # -Delta_j / 2 var2_normal_pdf(Delta_j)
+        diff = self._dPhi[:, blk] - self._dPhi[:, i:i + 1]    # [F, m] on the device
+        if order_of_derivative == 2:
+            diff = diff * diff
+        return self.eng.dgemm(diff.contiguous(), w.reshape(-1, 1).contiguous()).cpu().numpy().ravel()
+
+    def sum_Phi_vec(self, order_of_derivative, f, sigma):
+        """One sum_Phi per observation (random_fourier_sampler.py:96-102): [n_q] for order 0, [n_q, nFeatures] else."""
+        out = [self.sum_Phi(i, order_of_derivative, f, sigma) for i in self.obs_indices]
+        return None if any(o is None for o in out) else np.array(out)
+
     def update_omega_MAP(self):
         """Maximise S from a standard-normal start (:124-132).  The Hessian is diagonal, so the
         trust-region Newton of the reference reduces to per-coordinate safeguarded Newton steps."""

@@ -163,3 +163,29 @@ def test_rff_omega_map_entry_point(eng):
     assert it2 == 0 and np.array_equal(om2, om)
     with pytest.raises(RuntimeError):
         eng.rff_omega_map(Phi[:, :-1], rng.standard_normal(F), m, 0.3)
+
+
+def test_hsampler_sum_phi_vs_reference(golden):
+    """Hsampler.sum_Phi / sum_Phi_vec (random_fourier_sampler.py:62-102) on the fixture's basis against the reference's
+    own outputs: order 0 per query, orders 1 and 2 as nFeatures-vectors per query (<= 1e-12 of the largest entry)."""
+    from test_gpu_dropin import _model
+    from ppbo_amd.random_fourier_sampler import Hsampler
+    g, c = golden("smoke"), load_golden("compat_smoke")
+    gp, _ = _model(g)
+    gp.set_theta()
+    gp.xstar, gp.xstars_local = np.full(gp.D, 0.5), np.full((1, gp.D), 0.5)
+    F = g["rff_W"].shape[0]
+    hs = Hsampler(gp, F)
+    hs.W, hs.b = g["rff_W"].copy(), g["rff_b"].reshape(F, 1).copy()
+    hs.update_phi_X()
+    sig = float(g["theta"][0])
+    fw = hs.phi_X.T @ g["rff_omega"]
+    assert np.abs(fw - c["hs_f"]).max() <= 1e-12 * np.abs(c["hs_f"]).max()
+    for order in (0, 1, 2):
+        out = hs.sum_Phi_vec(order, c["hs_f"], sig)
+        ref = c[f"hs_sum_phi_{order}"]
+        assert out.shape == ref.shape, (order, out.shape, ref.shape)
+        assert np.abs(out - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), order
+    one = hs.sum_Phi(int(hs.obs_indices[1]), 1, c["hs_f"], sig)
+    assert np.abs(one - c["hs_sum_phi_1"][1]).max() <= 1e-12 * np.abs(c["hs_sum_phi_1"]).max()
+    assert hs.sum_Phi(0, 3, c["hs_f"], sig) is None

@@ -10,7 +10,9 @@ names:
       misc.regularize_covariance (misc.py:71-88, SVD round trip and sklearn shrinkage included) on a symmetric test
       matrix with three negative diagonal entries, for (reg_level, pos_diag) in {(1e-4, True), (0.1, True),
       (0.05, False)}; misc.pd_inverse (:96-100) of the regularised matrix before the diagonal was spoiled;
-      misc.is_positive_definite (:120-126) of that matrix (True) and of the spoiled one (False).
+      misc.is_positive_definite (:120-126) of that matrix (True) and of the spoiled one (False);
+      Hsampler.sum_Phi_vec(order, f, sigma) (random_fourier_sampler.py:62-102) for order 0, 1, 2 on the fixture's
+      basis (rff_W, rff_b) at f = Phi(X)^T rff_omega.
 
 usage: python tools/make_golden_r3.py compat smoke rq
 """
@@ -56,6 +58,18 @@ def compat(name):
     out["pd_reg"] = np.asarray(ref_misc.regularize_covariance(out["pd_in"].copy(), 1e-4))
     out["pd_inv"] = np.asarray(ref_misc.pd_inverse(out["pd_reg"].copy()))
     out["is_pd"] = np.array([ref_misc.is_positive_definite(out["pd_reg"]), ref_misc.is_positive_definite(K)])
+    # Hsampler.sum_Phi_vec (random_fourier_sampler.py:62-102) on the fixture's basis at f = Phi(X)^T omega
+    if "rff_W" in z:                               # SE fixtures only: the reference has no other spectral basis
+        import random_fourier_sampler as ref_rff
+        F = z["rff_W"].shape[0]
+        gp.xstar, gp.xstars_local = np.full(gp.D, 0.5), np.full((1, gp.D), 0.5)
+        hs = ref_rff.Hsampler(gp, F)
+        hs.W, hs.b = z["rff_W"].copy(), z["rff_b"].reshape(F, 1).copy()
+        hs.update_phi_X()
+        fw = np.asarray(hs.phi_X.T @ z["rff_omega"]).ravel()
+        out["hs_f"] = fw
+        for order in (0, 1, 2):
+            out[f"hs_sum_phi_{order}"] = np.asarray(hs.sum_Phi_vec(order, fw, sig), dtype=float)
     path = os.path.join(OUT, f"compat_{name}.npz")
     np.savez_compressed(path, **out)
     print(f"[compat_{name}] wrote {path} ({os.path.getsize(path) / 1e3:.0f} kB); is_pd = {out['is_pd']}")
