@@ -689,3 +689,28 @@ def test_every_dimension_bucket(eng, D, kernel):
         W = np.random.default_rng(3).standard_normal((F, D)) / th[1]
         b = np.random.default_rng(4).uniform(0, 2 * np.pi, F)
         assert np.abs(host(eng.rff_project(X, W, b, th[2])) - orc.rff_features(X, W, b, th[2])).max() <= 1e-12
+
+
+@pytest.mark.parametrize("m", [1, 3, 7, 15, 31, 63, 127])
+def test_variance_contraction_fast_path_star_sizes(eng, m):
+    """N = 256 and M = 256 are whole tiles, so the variance contraction takes the lean (aligned, in-bounds) main loop
+    with its per-wavefront K limit at every star size m + 1 that divides the 128-row tile: mean and variance against
+    the oracle's dense operator."""
+    D = 3
+    n_q = 256 // (m + 1)
+    th = [0.3, 0.6, 0.8]
+    X = orc.synthetic_design(n_q, D, m=m, seed=m)
+    N = X.shape[0]
+    assert N == 256
+    S0 = orc.gram(X, th, "SE_kernel")
+    Sinv0 = orc.pd_inverse(S0)
+    f_init = np.random.default_rng(m).multivariate_normal(np.zeros(N), S0, method="cholesky")
+    f0, _ = orc.fit_fmap_trust_exact(f_init, Sinv0, m, th[0], gtol=1e-9)
+    post = eng.posterior(X, th, "SE_kernel", eng.pd_inverse(eng.gram(X, th, "SE_kernel")), f0, m)
+    P0 = orc.posterior_covariance(Sinv0, f0, m, th[0])
+    A0 = orc.variance_operator(Sinv0, P0, faithful=False, lam=orc.lambda_dense(f0, m, th[0]))
+    Xc = np.random.default_rng(100 + m).random((256, D))
+    mu0, var0 = orc.predict_mean_var(Xc, X, th, Sinv0 @ f0, A0, "SE_kernel")
+    out = eng.predict(post, Xc)
+    assert rel(host(out["mu"]), mu0) < 1e-7
+    assert np.abs(host(out["var"]) - var0).max() <= 1e-7 * th[2] ** 2
