@@ -291,8 +291,9 @@ int ppbo_rff_terms(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, doub
 
 /* Hsampler.update_omega_MAP (src/random_fourier_sampler.py:124-132): maximise S from the start vector in d_omega[F]
  * (in: start, out: omega_MAP).  The reference hands -S to SciPy's trust-exact; S_hessian is diagonal, so the trust
- * region Newton reduces to per-coordinate steps g / max(-h, 1e-12) cut back to the radius, with SciPy's radius rules
- * (x1/4 below rho = 1/4, x2 above 3/4 on the boundary, accept above 0.15).  omega, gradient and Hessian diagonal stay
+ * region subproblem has the closed form s_i = g_i / (max(-h_i, 1e-12) + lam) with lam = 0 when the Newton step fits
+ * and the More-Sorensen root of |s(lam)| = radius otherwise, under SciPy's radius rules (x1/4 below rho = 1/4, x2
+ * above 3/4 on the boundary, accept above 0.15).  omega, gradient and Hessian diagonal stay
  * on the device; the host reads four scalars per iteration.  Stops on |grad S| < gtol, maxiter, or a collapsed radius. */
 int ppbo_rff_omega_map(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, double sigma, double* d_omega,
                        int maxiter, double gtol, double* h_S, double* h_gradnorm, int* h_iterations, void* stream);

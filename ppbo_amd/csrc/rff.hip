@@ -357,51 +357,65 @@ __global__ __launch_bounds__(1024) void rff_S_kernel(const double* __restrict__ 
   }
 }
 
-// One safeguarded Newton step of update_omega_MAP (random_fourier_sampler.py:124-132; the Hessian of S is diagonal):
-// step = g / max(-h, 1e-12) cut back to the trust radius, trial = omega + step, and the scalars the accept / reject
-// rule needs -- out[0] = |uncut step|, out[1] = predicted gain g.step - 1/2 step.(curv step), out[2] = |g|.
+// One trust-region step of update_omega_MAP (random_fourier_sampler.py:124-132).  The Hessian of S is diagonal, so the
+// subproblem trust-exact solves -- min -g.s + 1/2 s.(C s), |s| <= radius, C = diag(max(-h, 1e-12)) -- has the closed
+// form s_i = g_i / (c_i + lam): lam = 0 when the Newton step fits, otherwise the root of |s(lam)| = radius, found by
+// the More-Sorensen Newton iteration on 1/|s| - 1/radius (monotone from lam = 0 since every c_i + lam > 0).
+// trial = omega + s;  out[0] = |Newton step| (>= radius <=> the step is on the boundary), out[1] = predicted gain
+// g.s - 1/2 s.(C s), out[2] = |g|.
 __global__ __launch_bounds__(1024) void rff_newton_step_kernel(const double* __restrict__ omega, const double* __restrict__ g,
                                                                const double* __restrict__ h, int F, double radius,
                                                                double* __restrict__ trial, double* __restrict__ out) {
-  __shared__ double sh[3][16];
-  __shared__ double s_scale;
+  __shared__ double sh[2][16];
+  __shared__ double s_a, s_b;
   const int t = threadIdx.x;
+  auto block_sum2 = [&](double a, double b) {        // -> s_a, s_b on every thread
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if ((t & 63) == 0) { sh[0][t >> 6] = a; sh[1][t >> 6] = b; }
+    __syncthreads();
+    if (t == 0) {
+      double x = 0.0, y = 0.0;
+      for (int w = 0; w < 16; ++w) { x += sh[0][w]; y += sh[1][w]; }
+      s_a = x; s_b = y;
+    }
+    __syncthreads();
+  };
   double n2 = 0.0, g2 = 0.0;
   for (int f = t; f < F; f += 1024) {
-    const double curv = fmax(-h[f], 1e-12);
-    const double st = g[f] / curv;
+    const double c = fmax(-h[f], 1e-12), st = g[f] / c;
     n2 += st * st;
     g2 += g[f] * g[f];
   }
-  n2 = wave_sum(n2);
-  g2 = wave_sum(g2);
-  if ((t & 63) == 0) { sh[0][t >> 6] = n2; sh[1][t >> 6] = g2; }
-  __syncthreads();
-  if (t == 0) {
-    double a = 0.0, b = 0.0;
-    for (int w = 0; w < 16; ++w) { a += sh[0][w]; b += sh[1][w]; }
-    const double nrm = sqrt(a);
-    out[0] = nrm;
-    out[2] = sqrt(b);
-    s_scale = (nrm > radius) ? radius / nrm : 1.0;
+  block_sum2(n2, g2);
+  const double nrm = sqrt(s_a);
+  if (t == 0) { out[0] = nrm; out[2] = sqrt(s_b); }
+  double lam = 0.0;
+  if (nrm > radius) {
+    for (int it = 0; it < 40; ++it) {
+      double a = 0.0, b = 0.0;                       // |s|^2 and s.(C + lam)^-1 s
+      for (int f = t; f < F; f += 1024) {
+        const double d = fmax(-h[f], 1e-12) + lam, st = g[f] / d;
+        a += st * st;
+        b += st * st / d;
+      }
+      __syncthreads();                               // everyone has read s_a / s_b of the previous round
+      block_sum2(a, b);
+      const double sn = sqrt(s_a);
+      if (fabs(sn - radius) <= 1e-12 * radius || !(s_b > 0.0)) break;
+      lam += (s_a / s_b) * ((sn - radius) / radius);
+      if (lam < 0.0) lam = 0.0;
+    }
   }
-  __syncthreads();
-  const double scale = s_scale;
   double pred = 0.0;
   for (int f = t; f < F; f += 1024) {
-    const double curv = fmax(-h[f], 1e-12);
-    const double st = scale * (g[f] / curv);
+    const double c = fmax(-h[f], 1e-12), st = g[f] / (c + lam);
     trial[f] = omega[f] + st;
-    pred += g[f] * st - 0.5 * st * (curv * st);
+    pred += g[f] * st - 0.5 * st * (c * st);
   }
-  pred = wave_sum(pred);
-  if ((t & 63) == 0) sh[2][t >> 6] = pred;
   __syncthreads();
-  if (t == 0) {
-    double a = 0.0;
-    for (int w = 0; w < 16; ++w) a += sh[2][w];
-    out[1] = a;
-  }
+  block_sum2(pred, 0.0);
+  if (t == 0) out[1] = s_a;
 }
 
 // S (optional, into *d_S_out[0]), grad S and diag(S_hessian) at omega, enqueued only
