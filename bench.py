@@ -11,8 +11,10 @@ plus (N>1) one RCCL all-gather of the 16-byte (score, index) record.
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # the driver's form
     python bench.py --gpus 8 --config c4              # BASELINE config 4: 262144 candidates SHARDED over the ranks
 
---scaling weak (default except c4): every rank scores its own --candidates rows against the same replicated
-model.  --scaling strong (default for c4): --candidates is the job total, rank r scores rows shard_bounds(M, r, N).
+--scaling strong (default): --candidates is the JOB total -- BASELINE's metric is quoted at a fixed M (C3: 65536) on
+1/2/4/8 GPUs -- and rank r scores rows shard_bounds(M, r, N); `value` is that strong-scaling rate.  With more than one
+rank the same line also carries `weak_scaling_leg`: every rank scoring its own --candidates rows (timed right after).
+--scaling weak makes the weak leg the headline instead.
 """
 from __future__ import annotations
 
@@ -177,10 +179,10 @@ def per_query_breakdown(torch, reps=5):
 
 # BASELINE.json configs that have a committed design fixture: name, default candidate count, default scaling
 WORKLOADS = {
-    "c2": ("C2 Hartmann6-shaped", 16384, "weak"),
-    "c3": ("C3 Ackley-shaped", 65536, "weak"),
+    "c2": ("C2 Hartmann6-shaped", 16384, "strong"),
+    "c3": ("C3 Ackley-shaped", 65536, "strong"),
     "c4": ("C4 Levy-shaped", 262144, "strong"),
-    "c5": ("C5 camphor/Cu(111)-shaped", 65536, "weak"),
+    "c5": ("C5 camphor/Cu(111)-shaped", 65536, "strong"),
 }
 
 
@@ -209,7 +211,12 @@ def main():
                     help="design fixture to fit (c3 = Ackley-shaped N=2048, D=20: the configuration the metric is quoted on)")
     ap.add_argument("--candidates", type=int, default=0, help="0 = the config's own M (c3: 65536, c4: 262144 ...)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
-                    help="weak: --candidates per rank; strong: --candidates in total, sharded (default: per config)")
+                    help="strong (default): --candidates in total, sharded over the ranks; weak: --candidates per rank")
+    ap.add_argument("--collective", choices=["torch", "capi"], default="torch",
+                    help="torch: torch.distributed all_gather_into_tensor (nccl = RCCL) on device records + ppbo_argmax_combine; "
+                         "capi: the library's own RCCL communicator, one ppbo_search_sharded call per step")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl) and run the collective path even with ONE rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the RFF / line-acquisition side measurements")
     args = ap.parse_args()
@@ -235,7 +242,7 @@ def main():
     import torch
     import torch.distributed as dist
     from ppbo_amd.engine import Engine, SCORE_POINTWISE_EI
-    from ppbo_amd.dist import allgather_argmax, shard_bounds
+    from ppbo_amd.dist import ShardedSearch, shard_bounds
 
     if not torch.cuda.is_available():
         sys.exit("bench.py: no ROCm GPU visible (torch.cuda.is_available() is False); the product has no CPU path")
@@ -244,9 +251,15 @@ def main():
     # exercises the whole multi-rank control flow (sharding, barriers, max-over-ranks timing, the argmax exchange)
     share_gpu = os.environ.get("PPBO_BENCH_SHARE_GPU") == "1"
     gpu_index = 0 if share_gpu else local_rank
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_PORT" not in os.environ:        # --force-dist outside torchrun: a free loopback port
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         torch.cuda.set_device(gpu_index)
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -408,7 +421,10 @@ def main():
                 "frac_of_floor": floor / stream}
 
     # ---- candidates resident in HBM ----------------------------------------------------
-    Xc = eng.dev(np.random.default_rng(1 + rank).random((M, D)))
+    if scaling == "strong":      # ONE job-wide candidate set (default_rng(1)); this rank holds its row block
+        Xc = eng.dev(np.random.default_rng(1).random((M_arg, D))[row_lo:row_hi])
+    else:
+        Xc = eng.dev(np.random.default_rng(1 + rank).random((M, D)))
     mustar = float(np.max(g["mu"]))
 
     # ---- steady-state rates of the HBM-bound kernels (rank 0), each under its own load (see burst_ms) ---------
@@ -426,35 +442,76 @@ def main():
             Xg = eng.dev(np.random.default_rng(7).random((Ng, D)))
             gram_sizes[str(Ng)] = gram_burst(Xg, 20)
             del Xg
+    # ---- the timed region: K steps of the sharded search, nothing else -------------------------------------
+    # A step = score this rank's rows (kstar, quadform, score + its own argmax: three launches), all-gather the
+    # 16-byte device records, reduce, read ONE record back.  The persistent tensors live in `search`; the library's
+    # event brackets are OFF here (they cost a few us per step) -- the per-kernel durations come from an identical
+    # bracketed pass right after.
+    search = ShardedSearch(eng, post, Xc, row_lo, SCORE_POINTWISE_EI, mustar, collective=args.collective,
+                           host_collective=share_gpu)
+
+    def timed_steps(srch, steps, after_warmup=None):
+        for _ in range(args.warmup):
+            srch.step()
+        if after_warmup is not None:
+            after_warmup()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = srch.step()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, res
+
+    elapsed, best = timed_steps(search, args.steps)
+    # the same steps again with the library's HIP-event brackets on (on the stream the kernels are launched on): the
+    # live per-kernel durations behind `roofline`; its wall time is reported beside the unbracketed one
     eng.profile(True)
-
-    def step():
-        out = eng.predict(post, Xc, score=SCORE_POINTWISE_EI, mustar=mustar, want_mu=False, want_var=False,
-                          want_score=False, want_best=True)
-        gidx = out["best_idx"] + row_lo if out["best_idx"] >= 0 else -1     # an empty shard must not alias a neighbour's row
-        return allgather_argmax(out["best_val"], gidx, device=coll_dev, engine=eng)
-
-    for _ in range(args.warmup):
-        step()
-    eng.profile_reset()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        best = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed_bracketed, _ = timed_steps(search, args.steps, after_warmup=eng.profile_reset)
     qf_ms, qf_n = eng.profile_read("quadform")
     ks_ms, ks_n = eng.profile_read("kstar")
     sc_ms, sc_n = eng.profile_read("score")
     eng.profile(False)
+    # the other leg (every rank scoring --candidates rows of its own), same protocol, for the side key
+    other_leg = None
+    if world > 1:
+        if scaling == "strong":
+            Xo = eng.dev(np.random.default_rng(101 + rank).random((M_arg, D)))
+            o_lo, o_total, o_name = rank * M_arg, M_arg * world, "weak"
+        else:
+            lo_s, hi_s = shard_bounds(M_arg, rank, world)
+            Xo = eng.dev(np.random.default_rng(1).random((M_arg, D))[lo_s:hi_s])
+            o_lo, o_total, o_name = lo_s, M_arg, "strong"
+        other = ShardedSearch(eng, post, Xo, o_lo, SCORE_POINTWISE_EI, mustar, collective="torch",
+                              host_collective=share_gpu)
+        o_elapsed, _ = timed_steps(other, args.steps)
+        other_leg = {"scaling": o_name, "value": o_total * args.steps / o_elapsed, "unit": "evals/s",
+                     "ms_per_step": o_elapsed / args.steps * 1e3, "M_total": o_total, "M_per_gpu": int(Xo.shape[0])}
+        del Xo, other
+    # the collective alone (rank 0 reports): the record is already on the device, so this is all-gather + reduction +
+    # 16-byte read-back + the host's wait, i.e. the fixed cost a step pays on top of its kernels
+    coll_us = None
+    if use_dist and not share_gpu:
+        rec = eng.predict_record(post, Xc[:256], SCORE_POINTWISE_EI, mustar, row_lo)
+        gath = eng.empty(2 * world)
+        for _ in range(5):
+            dist.all_gather_into_tensor(gath, rec)
+            eng.argmax_combine(gath)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            dist.all_gather_into_tensor(gath, rec)
+            eng.argmax_combine(gath)
+        torch.cuda.synchronize()
+        coll_us = (time.perf_counter() - t0) / 200 * 1e6
 
     # ---- secondary rows of SURVEY 8d (rank 0 only, outside the timed region) ------------
     secondary = {}
@@ -530,8 +587,17 @@ def main():
             "config": {"workload": f"{wl_name}: N={N} obs rows (m={m}), D={D}, M={M_total} candidates in total "
                                    f"({M} on rank 0), {kern} theta={list(map(float, th))}", "name": args.config,
                        "N": N, "D": D, "M_total": M_total, "M_per_gpu": M,
-                       "parallelism": f"candidates sharded x{world} ({scaling}), model replicated, 1 all-gather/step"
-                                      + (" [TEST MODE: ranks share one GPU, gloo]" if share_gpu else "")},
+                       "parallelism": f"candidates sharded x{world} ({scaling} scaling: M_total fixed at {M_total})"
+                                      if scaling == "strong" else
+                                      f"candidates sharded x{world} (weak scaling: {M} per GPU)",
+                       "model_state": "replicated (every rank runs the same deterministic fit)",
+                       "collective": ("none (single process)" if not use_dist else
+                                      "gloo on host records [TEST MODE: ranks share one GPU]" if share_gpu else
+                                      "1 all-gather of a 16-byte device record per step, " +
+                                      ("torch.distributed nccl (RCCL) + ppbo_argmax_combine" if args.collective == "torch"
+                                       else "the library's own RCCL communicator (ppbo_search_sharded)"))},
+            "ms_per_step_with_event_brackets": elapsed_bracketed / args.steps * 1e3,
+            "collective_roundtrip_us": coll_us,
             "gp_fit_ms": gp_fit_ms, "gp_fit_ms_runs": fit_runs, "gp_fit_start": fit_start, "gp_fit_iterations": st["iterations"],
             "gp_fit_cholesky": st["n_cholesky"],
             "replicated_fit_bitwise_equal": replicated_equal,
@@ -562,6 +628,7 @@ def main():
             },
             "secondary": secondary,
             "best": {"value": best[0], "index": best[1]},
+            ("weak_scaling_leg" if scaling == "strong" else "strong_scaling_leg"): other_leg,
         }
         # `traffic` needs rocprofv3 --pmc passes and cannot be measured from inside this process: it stays null.
         # The last committed PMC capture is quoted beside it ONLY while the kernel sources are the ones it was
@@ -599,7 +666,8 @@ def main():
             chk = eng.predict(post_ref, Xs, want_best=False)
             line["cpu_baseline"] = cpu_baseline(g, 2048, gpu_check=(Xs, chk["mu"].cpu().numpy(), chk["var"].cpu().numpy()))
         print(json.dumps(line))
-    if world > 1:
+    search.close()
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PPBO_ABI_VERSION 3
+#define PPBO_ABI_VERSION 4
 #define PPBO_ERR_NOT_PD 1001
 
 typedef struct ppbo_ctx ppbo_ctx;
@@ -160,6 +160,11 @@ typedef struct ppbo_fit_opts {
   int verbose;
   double initial_radius;   /* first trust radius; <= 0: SciPy's default 1.0 (what the reference runs with) */
   int lbfgs_max_evals;     /* ppbo_fit_fmap_whitened: evaluation budget of the whitened pre-phase; <= 0: 4000 */
+  int judge_by_gradient_below_noise;  /* 0 (what ppbo_fit_fmap's callers pass): SciPy trust-exact's acceptance and
+                            * radius rules throughout (actual / predicted decrease).  1 (set internally by
+                            * ppbo_fit_fmap_whitened for its finishing phase): a step whose predicted decrease is below
+                            * the rounding noise of the objective difference is accepted when it lowers |grad| --
+                            * next to the optimum actual / predicted is a random number */
 } ppbo_fit_opts;
 typedef struct ppbo_fit_stats {
   int iterations;   /* outer trust-region iterations */
@@ -230,6 +235,14 @@ typedef struct ppbo_model {
 int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
                  int score_kind, double mustar, double* d_mu, double* d_var, double* d_score,
                  double* h_best_val, int64_t* h_best_idx, void* stream);
+
+/* The same scoring passes for ONE SHARD of a sharded candidate search: nothing comes back to the
+ * host and nothing synchronises.  d_record[2] (device) receives (best score, index_offset + its FIRST row index as
+ * a double, exact below 2^53) -- (NaN, -1) when no candidate has a non-NaN score -- i.e. exactly the 16-byte record
+ * that ppbo_argmax_allgather_record / torch.distributed all-gather.  The score launch reduces its own best (its last
+ * workgroup to retire merges the per-block records): kstar, quadform, score are the only launches. */
+int ppbo_predict_record(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
+                        int score_kind, double mustar, int64_t index_offset, double* d_record, void* stream);
 
 /* full predictive covariance of small sets (the G=70 line grid of EI):
  * d_cov[M,M] = (1-s)K(Xc,Xc) + s sigma_f^2 I - K*^T A K*  (src/gp_model.py:447-450) */
@@ -341,6 +354,17 @@ int ppbo_dist_init(ppbo_ctx* ctx, const void* h_id128, int rank, int world);
 int ppbo_dist_destroy(ppbo_ctx* ctx);
 int ppbo_argmax_allgather(ppbo_ctx* ctx, double local_val, int64_t local_global_idx, double* h_best_val,
                           int64_t* h_best_idx, void* stream);
+/* the same exchange fed from DEVICE memory (d_record[2] as written by ppbo_predict_record): no host value is
+ * uploaded first; all-gather, reduction and the 16-byte read-back run behind each other on `stream`. */
+int ppbo_argmax_allgather_record(ppbo_ctx* ctx, const double* d_record, double* h_best_val, int64_t* h_best_idx,
+                                 void* stream);
+/* one whole sharded search step in ONE call: ppbo_predict_record on this rank's M rows (global row index =
+ * index_offset + local row), ncclAllGather of the records, reduction, one 16-byte read-back, ONE host wait.
+ * Every rank returns the job-wide (best score, global index).  Without ppbo_dist_init (a single-process search)
+ * the collective is skipped.  Replaces the sequential search of mu_star (src/gp_model.py:415-437) over a sharded
+ * candidate set; the reference itself is process-per-run (ppbo_numerical_main.py:192-193). */
+int ppbo_search_sharded(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
+                        double mustar, int64_t index_offset, double* h_best_val, int64_t* h_best_idx, void* stream);
 /* the reduction alone, for callers that run the all-gather themselves (torch.distributed in ppbo_amd/dist.py):
  * d_records[world][2] = (value, global index as a double) per rank, already gathered in device memory; one
  * single-wavefront kernel applies the rule above and ONE 16-byte record is copied back. */

@@ -22,7 +22,7 @@ SCORE_MEAN, SCORE_POINTWISE_EI, SCORE_VARIANCE = 0, 1, 2
 
 class FitOpts(C.Structure):
     _fields_ = [("gtol", C.c_double), ("maxiter", C.c_int), ("verbose", C.c_int), ("initial_radius", C.c_double),
-                ("lbfgs_max_evals", C.c_int)]
+                ("lbfgs_max_evals", C.c_int), ("judge_by_gradient_below_noise", C.c_int)]
 
 
 class FitStats(C.Structure):
@@ -66,6 +66,7 @@ SIGNATURES = {
     "ppbo_T_and_grad": [_vp, _vp, _vp, _i, _i, _d, C.POINTER(_d), _vp, _vp],
     "ppbo_posterior": [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_predict": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _vp, _vp, _vp, C.POINTER(_d), C.POINTER(_i64), _vp],
+    "ppbo_predict_record": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _i64, _vp, _vp],
     "ppbo_predict_cov": [_vp, C.POINTER(Model), _vp, _i, _d, _vp, _vp, _vp],
     "ppbo_mean_grad": [_vp, C.POINTER(Model), _vp, C.c_int64, _vp, _vp, _vp],
     "ppbo_mean_search": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _i, _d, _vp, _vp, C.POINTER(_i), _vp],
@@ -85,12 +86,14 @@ SIGNATURES = {
     "ppbo_dist_init": [_vp, _vp, _i, _i],
     "ppbo_dist_destroy": [_vp],
     "ppbo_argmax_allgather": [_vp, _d, _i64, C.POINTER(_d), C.POINTER(_i64), _vp],
+    "ppbo_argmax_allgather_record": [_vp, _vp, C.POINTER(_d), C.POINTER(_i64), _vp],
+    "ppbo_search_sharded": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _i64, C.POINTER(_d), C.POINTER(_i64), _vp],
     "ppbo_argmax_combine": [_vp, _vp, _i, C.POINTER(_d), C.POINTER(_i64), _vp],
     "ppbo_dgemm": [_vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i, _d, _vp, _i, _vp],
 }
 
 _lib = None
-ABI_VERSION = 3     # must equal PPBO_ABI_VERSION of include/ppbo_hip.h
+ABI_VERSION = 4     # must equal PPBO_ABI_VERSION of include/ppbo_hip.h
 
 
 def _check_stamp():

@@ -1,4 +1,6 @@
 // Context management and error plumbing of libppbo_hip.so.
+#include <chrono>
+
 #include "common.h"
 
 int ppbo_set_error(ppbo_ctx* ctx, int code, const char* fmt, ...) {
@@ -43,6 +45,55 @@ void* ppbo_pinned(ppbo_ctx* ctx, size_t bytes) {
   ctx->pinned = p;
   ctx->pinned_bytes = bytes;
   return p;
+}
+
+unsigned* ppbo_ticket_counter(ppbo_ctx* ctx) {
+  if (ctx->ticket) return ctx->ticket;
+  void* p = nullptr;
+  if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) {   // synchronous: once per ctx
+    if (p) (void)hipFree(p);
+    ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "ticket counter allocation failed");
+    return nullptr;
+  }
+  ctx->ticket = (unsigned*)p;
+  return ctx->ticket;
+}
+
+int ppbo_host_record(ppbo_ctx* ctx, PpboHostRecord* out) {
+  if (!ctx->hostrec) {
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, 256, hipHostMallocMapped) != hipSuccess)
+      return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "host-mapped result record: hipHostMalloc failed");
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipHostFree(h);
+      return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "host-mapped result record: no device pointer");
+    }
+    std::memset(h, 0, 256);
+    ctx->hostrec = (double*)h;
+    ctx->hostrec_dev = (double*)d;
+  }
+  out->d_rec = ctx->hostrec_dev;
+  out->d_flag = reinterpret_cast<unsigned long long*>(ctx->hostrec_dev + 2);
+  out->h_rec = ctx->hostrec;
+  out->epoch = ++ctx->hostrec_epoch;
+  return 0;
+}
+
+int ppbo_host_record_wait(ppbo_ctx* ctx, const PpboHostRecord& r, hipStream_t s) {
+  const volatile unsigned long long* flag = reinterpret_cast<const volatile unsigned long long*>(ctx->hostrec + 2);
+  // the kernels in front of the publishing one take 0.5 ... 5 ms; poll for a bounded time, then let the runtime wait
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    if (*flag == r.epoch) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return 0; }
+    __builtin_ia32_pause();
+    if ((spins & 0xfff) == 0xfff &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+  }
+  PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  if (*flag == r.epoch) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return 0; }
+  return ppbo_set_error(ctx, (int)hipErrorUnknown, "the result record was never published (flag %llu, expected %llu)",
+                        (unsigned long long)*flag, r.epoch);
 }
 
 void ppbo_lds_limit(ppbo_ctx* ctx, const void* kernel_fn, int bytes) {
@@ -97,6 +148,8 @@ int ppbo_ctx_destroy(ppbo_ctx* ctx) {
   for (int i = 0; i < ppbo_ctx::WS_COUNT; ++i)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->ticket) (void)hipFree(ctx->ticket);
+  if (ctx->hostrec) (void)hipHostFree(ctx->hostrec);
   for (int i = 0; i < ppbo_ctx::PF_COUNT; ++i)
     for (auto& pr : ctx->pf_events[i]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   }

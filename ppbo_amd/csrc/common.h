@@ -37,7 +37,29 @@ struct ppbo_ctx {
   // tuning knobs, read from the environment once per ctx (ppbo_ctx_create); defaults = measured best
   int qf_variant = 2, qf_order = 258, potrf_gen = 3, rff_nt = 0, gram_variant = -1, rff_score_mfma = 1;
   ppbo_dist_state* dist = nullptr;   // set by ppbo_dist_init
+  unsigned* ticket = nullptr;        // device word, zero between launches: the "last workgroup" ticket of score_kernel
+  // host-mapped (pinned, device-visible) result record: [0] value, [1] index as a double, [2] the epoch flag the
+  // publishing kernel raises last; the host polls it (ppbo_host_record_wait)
+  double* hostrec = nullptr;         // host address
+  double* hostrec_dev = nullptr;     // the same memory as the device sees it
+  unsigned long long hostrec_epoch = 0;
 };
+
+struct PpboHostRecord {
+  double* d_rec;                     // device view of the record (2 doubles)
+  unsigned long long* d_flag;        // device view of the flag
+  const volatile double* h_rec;      // host view
+  unsigned long long epoch;          // the value the flag takes when the record is complete
+};
+// a fresh epoch on the ctx's host-mapped record (allocated on first use)
+int ppbo_host_record(ppbo_ctx* ctx, PpboHostRecord* out);
+// spin until the kernel enqueued on `s` has raised the flag to the record's epoch; falls back to a stream
+// synchronisation (and reports an error if the flag still is not there: the kernel did not run to completion)
+int ppbo_host_record_wait(ppbo_ctx* ctx, const PpboHostRecord& r, hipStream_t s);
+// predict.hip, for dist.hip: one shard's scoring passes with the record published to host-mapped memory
+int ppbo_predict_record_publish(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
+                                double mustar, int64_t index_offset, double* d_record, unsigned long long* d_flag,
+                                unsigned long long epoch, hipStream_t s);
 
 // Every extern "C" entry runs on its ctx's device and leaves the caller's current device as it found it.
 struct PpboDeviceGuard {
@@ -76,6 +98,8 @@ int ppbo_set_error(ppbo_ctx* ctx, int code, const char* fmt, ...);
 // returns a device pointer of at least `bytes` (contents undefined); nullptr on failure
 void* ppbo_workspace(ppbo_ctx* ctx, int slot, size_t bytes);
 void* ppbo_pinned(ppbo_ctx* ctx, size_t bytes);
+// the ctx's ticket counter (device, 4 bytes used, zeroed once at allocation; whoever draws the last ticket resets it)
+unsigned* ppbo_ticket_counter(ppbo_ctx* ctx);
 // raise a kernel's dynamic-LDS limit to `bytes` once per ctx (i.e. once per device)
 void ppbo_lds_limit(ppbo_ctx* ctx, const void* kernel_fn, int bytes);
 

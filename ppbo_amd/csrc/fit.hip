@@ -862,6 +862,7 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
   const double gtol = (opts && opts->gtol > 0) ? opts->gtol : 1e-4;
   const int maxiter = (opts && opts->maxiter > 0) ? opts->maxiter : 200 * N;
   const int verbose = opts ? opts->verbose : 0;
+  const bool judge_noise = opts && opts->judge_by_gradient_below_noise != 0;
 
   FitWork W{};
   W.ctx = ctx; W.s = (hipStream_t)stream; W.Sinv = d_Sigma_inv;
@@ -1074,7 +1075,9 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
     // Newton step would be rejected and the radius quartered until it cuts the step (seen when the fit is
     // started from the whitened pre-phase's result with a gtol below that phase's floor): there the step is
     // judged by what it does to the gradient instead.
-    if (pred < 1e-11 * std::fmax(1.0, std::fabs(phi_of(C))) && T.gn2 < C.gn2) rho = 1.0;
+    // Only as the whitened search's finisher (opts->judge_by_gradient_below_noise): called on its own, this routine
+    // follows SciPy's acceptance and radius rules to the letter.
+    if (judge_noise && pred < 1e-11 * std::fmax(1.0, std::fabs(phi_of(C))) && T.gn2 < C.gn2) rho = 1.0;
     const double old_radius = radius;
     if (!(rho >= 0.25)) { if (!chord) radius *= 0.25; }   // a poor chord step blames the stale Hessian, not the radius
     else if (rho > 0.75 && boundary) radius = std::fmin(2.0 * radius, rmax);
@@ -1202,7 +1205,10 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
   }
   // finisher: the exact trust-region Newton from there (no iteration at all when |grad_f| < gtol already holds)
   ppbo_fit_stats tr{};
-  const int rc = ppbo_fit_fmap(ctx, d_Sigma_inv, N, m, sigma, d_fMAP, opts, d_fMAP, &tr, stream);
+  ppbo_fit_opts fin{};
+  if (opts) fin = *opts;
+  fin.judge_by_gradient_below_noise = 1;
+  const int rc = ppbo_fit_fmap(ctx, d_Sigma_inv, N, m, sigma, d_fMAP, &fin, d_fMAP, &tr, stream);
   if (h_stats) {
     *h_stats = tr;
     h_stats->lbfgs_iterations = lb_iters;

@@ -16,7 +16,7 @@
 //   Workgroups are ordered candidate-tile-fastest in chunks of 64 tiles (PPBO_QF_ORDER, default 258):
 //   all resident workgroups stream the same G row panel out of L2 while their K* chunk sits in the
 //   Infinity Cache.  PPBO_QF_VARIANT (default 2) selects the measured tile shapes, see DESIGN.md.
-// Pass 3 (score_kernel): slab sums -> var, score, per-block argmax; (argmax_final_kernel) -> 1 value.
+// Pass 3 (score_kernel): slab sums -> var, score, per-block argmax; its last workgroup -> 1 value.
 #include "gemm_f64.h"
 #include "linalg.h"
 #include "score.h"
@@ -544,10 +544,13 @@ int pick_split(int M, int n_q) {
 
 extern "C" {
 
-int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
-                 double mustar, double* d_mu, double* d_var, double* d_score, double* h_best_val,
-                 int64_t* h_best_idx, void* stream) {
-  PPBO_ENTER(ctx);
+// the scoring passes of ppbo_predict / ppbo_predict_record: per 65536-candidate chunk kstar -> quadform -> score (the
+// score launch also reduces the chunk's best: its last workgroup merges the per-block records).  Leaves the per-chunk
+// bests in *chunk_best_out (device); with d_record and ONE chunk the score launch writes the record itself.
+static int predict_passes(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
+                          double mustar, double* d_mu, double* d_var, double* d_score, bool want_best,
+                          double* d_record, int64_t record_offset, Best** chunk_best_out, int* n_chunks_out,
+                          hipStream_t s, unsigned long long* publish = nullptr, unsigned long long epoch = 0) {
   if (int rc = check_model(ctx, model)) return rc;
   PPBO_REQUIRE(ctx, d_Xc != nullptr && M > 0, "candidates");
   PPBO_REQUIRE(ctx, score_kind >= 0 && score_kind <= 2, "score_kind");
@@ -555,7 +558,6 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
   PPBO_REQUIRE(ctx, want_var || (d_var == nullptr && score_kind == PPBO_SCORE_MEAN),
                "variance / EI scores need model->d_G");
   PPBO_REQUIRE(ctx, !want_var || (model->d_lam_diag && model->d_lam_off), "model Lambda");
-  hipStream_t s = (hipStream_t)stream;
   const int N = model->N, mblk = model->m + 1, n_q = N / mblk;
   const int64_t chunk_cap = 65536;
   const int64_t n_chunks = (M + chunk_cap - 1) / chunk_cap;
@@ -576,11 +578,15 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
   const size_t part_doubles = (size_t)(2 * n_split_eff + ntm) * Mc_max;
   double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_PART, part_doubles * sizeof(double));
   if (!part) return (int)hipErrorOutOfMemory;
-  const int sblocks_max = (Mc_max + 255) / 256;
+  const int sblocks_max = score_blocks(Mc_max);
   Best* bests = (Best*)ppbo_workspace(ctx, ppbo_ctx::WS_SMALL, (size_t)(sblocks_max + n_chunks) * sizeof(Best));
   if (!bests) return (int)hipErrorOutOfMemory;
   Best* chunk_best = bests + sblocks_max;
-
+  unsigned* ticket = nullptr;
+  if (want_best) {
+    ticket = ppbo_ticket_counter(ctx);
+    if (!ticket) return (int)hipErrorOutOfMemory;
+  }
 
   for (int64_t ch = 0; ch < n_chunks; ++ch) {
     const int64_t c_beg = ch * chunk_cap;
@@ -598,20 +604,74 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
       PpboProfScope pf(ctx, ppbo_ctx::PF_QUADFORM, s);
       if (int rc = dispatch_quadform(ctx, model->d_G, N, Kt, ldk, Mc, mblk, slab, s)) return rc;
     }
-    const int sblocks = (Mc + 255) / 256;
+    const int sblocks = score_blocks(Mc);
     PpboProfScope pfs(ctx, ppbo_ctx::PF_SCORE, s);
-    score_kernel<<<sblocks, 256, 0, s>>>(mu_part, n_split_eff, t_part, want_var ? slab : nullptr, ntm, Mc,
-                                         model->theta[2] * model->theta[2], score_kind, mustar,
-                                         (long long)c_beg, d_mu ? d_mu + c_beg : nullptr,
-                                         d_var ? d_var + c_beg : nullptr, d_score ? d_score + c_beg : nullptr,
-                                         bests);
-    PPBO_LAUNCH_CHECK(ctx);
-    argmax_final_kernel<<<1, 256, 0, s>>>(bests, sblocks, chunk_best + ch);
+    const bool one = (n_chunks == 1);
+    score_kernel<<<sblocks, SC_THREADS, 0, s>>>(mu_part, n_split_eff, t_part, want_var ? slab : nullptr, ntm, Mc,
+                                                model->theta[2] * model->theta[2], score_kind, mustar,
+                                                (long long)c_beg, d_mu ? d_mu + c_beg : nullptr,
+                                                d_var ? d_var + c_beg : nullptr, d_score ? d_score + c_beg : nullptr,
+                                                want_best ? bests : nullptr, ticket, chunk_best + ch,
+                                                one ? d_record : nullptr, (long long)record_offset,
+                                                one ? publish : nullptr, epoch);
     PPBO_LAUNCH_CHECK(ctx);
   }
-  if (int rc = merge_chunk_bests(ctx, chunk_best, (int)n_chunks, h_best_val, h_best_idx, s)) return rc;
+  if (d_record && n_chunks > 1) {
+    best_record_kernel<<<1, 64, 0, s>>>(chunk_best, (int)n_chunks, (long long)record_offset, d_record, publish, epoch);
+    PPBO_LAUNCH_CHECK(ctx);
+  }
+  *chunk_best_out = chunk_best;
+  *n_chunks_out = (int)n_chunks;
   return 0;
 }
+
+int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
+                 double mustar, double* d_mu, double* d_var, double* d_score, double* h_best_val,
+                 int64_t* h_best_idx, void* stream) {
+  PPBO_ENTER(ctx);
+  hipStream_t s = (hipStream_t)stream;
+  Best* chunk_best = nullptr;
+  int n_chunks = 0;
+  const bool want_best = h_best_val || h_best_idx;
+  if (!want_best)
+    return predict_passes(ctx, model, d_Xc, M, score_kind, mustar, d_mu, d_var, d_score, false, nullptr, 0,
+                          &chunk_best, &n_chunks, s);
+  // the best comes back through the ctx's host-mapped record (written by the last score workgroup, flag polled by the
+  // host) instead of a device-to-host copy + stream synchronisation
+  PpboHostRecord hr;
+  if (int rc = ppbo_host_record(ctx, &hr)) return rc;
+  if (int rc = predict_passes(ctx, model, d_Xc, M, score_kind, mustar, d_mu, d_var, d_score, true, hr.d_rec, 0,
+                              &chunk_best, &n_chunks, s, hr.d_flag, hr.epoch))
+    return rc;
+  if (int rc = ppbo_host_record_wait(ctx, hr, s)) return rc;
+  if (h_best_val) *h_best_val = hr.h_rec[1] < 0.0 ? 0.0 : hr.h_rec[0];
+  if (h_best_idx) *h_best_idx = (int64_t)hr.h_rec[1];
+  return 0;
+}
+
+int ppbo_predict_record(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
+                        double mustar, int64_t index_offset, double* d_record, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_record != nullptr, "d_record");
+  Best* chunk_best = nullptr;
+  int n_chunks = 0;
+  return predict_passes(ctx, model, d_Xc, M, score_kind, mustar, nullptr, nullptr, nullptr, true, d_record,
+                        index_offset, &chunk_best, &n_chunks, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// internal (dist.hip): ppbo_predict_record whose record lives in host-mapped memory, the flag raised after it
+int ppbo_predict_record_publish(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
+                                double mustar, int64_t index_offset, double* d_record, unsigned long long* d_flag,
+                                unsigned long long epoch, hipStream_t s) {
+  Best* chunk_best = nullptr;
+  int n_chunks = 0;
+  return predict_passes(ctx, model, d_Xc, M, score_kind, mustar, nullptr, nullptr, nullptr, true, d_record,
+                        index_offset, &chunk_best, &n_chunks, s, d_flag, epoch);
+}
+
+extern "C" {
 
 int ppbo_predict_cov(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int M, double shrink,
                      double* d_mu, double* d_cov, void* stream) {
@@ -635,8 +695,8 @@ int ppbo_predict_cov(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc,
   dispatch_kstar(model, d_Xc, M, Kt, ld, part, nullptr, q_per_split, n_split_eff, false, s);
   PPBO_LAUNCH_CHECK(ctx);
   if (d_mu) {
-    score_kernel<<<(M + 255) / 256, 256, 0, s>>>(part, n_split_eff, nullptr, nullptr, 0, M, 0.0, PPBO_SCORE_MEAN,
-                                                 0.0, 0, d_mu, nullptr, nullptr, nullptr);
+    score_kernel<<<score_blocks(M), SC_THREADS, 0, s>>>(part, n_split_eff, nullptr, nullptr, 0, M, 0.0, PPBO_SCORE_MEAN,
+                                                        0.0, 0, d_mu, nullptr, nullptr, nullptr);
     PPBO_LAUNCH_CHECK(ctx);
   }
   // prior block with the reference's shrinkage (gp_model.py:447)
@@ -701,8 +761,8 @@ int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
     const int M = Bc * G;
     const double* xg = d_grid + (size_t)b0 * G * D;
     dispatch_kstar(model, xg, M, Kt, ld, part, nullptr, q_per_split, n_split_eff, false, s);
-    score_kernel<<<(M + 255) / 256, 256, 0, s>>>(part, n_split_eff, nullptr, nullptr, 0, M, 0.0, PPBO_SCORE_MEAN, 0.0,
-                                                 0, mu, nullptr, nullptr, nullptr);
+    score_kernel<<<score_blocks(M), SC_THREADS, 0, s>>>(part, n_split_eff, nullptr, nullptr, 0, M, 0.0, PPBO_SCORE_MEAN,
+                                                        0.0, 0, mu, nullptr, nullptr, nullptr);
     switch (model->kernel_id) {
       case PPBO_KERNEL_SE: line_prior_kernel<PPBO_KERNEL_SE><<<Bc, 256, 0, s>>>(xg, G, D, p, shrink, cov); break;
       case PPBO_KERNEL_RQ: line_prior_kernel<PPBO_KERNEL_RQ><<<Bc, 256, 0, s>>>(xg, G, D, p, shrink, cov); break;

@@ -513,7 +513,7 @@ int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const do
   n_split = (F + f_per_split - 1) / f_per_split;
   double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_PART, (size_t)n_split * Mc_max * sizeof(double));
   if (!part) return (int)hipErrorOutOfMemory;
-  const int sblocks_max = (Mc_max + 255) / 256;
+  const int sblocks_max = score_blocks(Mc_max);
   Best* bests = (Best*)ppbo_workspace(ctx, ppbo_ctx::WS_SMALL, (size_t)(sblocks_max + n_chunks) * sizeof(Best));
   if (!bests) return (int)hipErrorOutOfMemory;
   Best* chunk_best = bests + sblocks_max;
@@ -554,8 +554,8 @@ int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const do
 #undef RS_LAUNCH
     }
     PPBO_LAUNCH_CHECK(ctx);
-    const int sblocks = (Mc + 255) / 256;
-    score_kernel<<<sblocks, 256, 0, s>>>(part, n_split, nullptr, nullptr, 0, Mc, 0.0, PPBO_SCORE_MEAN, 0.0,
+    const int sblocks = score_blocks(Mc);
+    score_kernel<<<sblocks, SC_THREADS, 0, s>>>(part, n_split, nullptr, nullptr, 0, Mc, 0.0, PPBO_SCORE_MEAN, 0.0,
                                          (long long)c_beg, nullptr, nullptr, d_score ? d_score + c_beg : nullptr,
                                          bests);
     argmax_final_kernel<<<1, 256, 0, s>>>(bests, sblocks, chunk_best + ch);
@@ -587,7 +587,7 @@ int ppbo_rff_omega_map(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, 
   hipStream_t s = (hipStream_t)stream;
   // omega / gradient / Hessian diagonal of the accepted point and of the trial point, 4 scalars, pinned read-back
   double* buf = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH_SMALL, ((size_t)6 * F + 8) * sizeof(double));
-  double* host = (double*)ppbo_pinned(ctx, (64 + 8) * sizeof(double));
+  double* host = (double*)ppbo_pinned(ctx, (64 + 8) * sizeof(double));   // out: 5 of its 8 doubles are used
   if (!buf || !host) return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "omega_MAP workspace");
   host += 64;                                    // the first 64 doubles of the pinned block belong to the fit
   double *om = buf, *g = buf + F, *h = buf + 2 * F, *omt = buf + 3 * F, *gt = buf + 4 * F, *ht = buf + 5 * F;
@@ -598,16 +598,21 @@ int ppbo_rff_omega_map(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, 
   PPBO_HIP_CHECK(ctx, hipMemcpyAsync(host, sc, sizeof(double), hipMemcpyDeviceToHost, s));
   PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
   double S = host[0], radius = 1.0, gn = INFINITY;
+  bool gn_current = false;                       // gn belongs to the point in `om` (else: to the one before the last acceptance)
   int it = 0;
   for (; it < maxiter; ++it) {
-    // the step from the accepted point and, speculatively, the terms at the trial point: ONE read-back per iteration
+    if (gn_current && gn < gtol) break;          // the accepted point is already stationary: no trial evaluation is paid for
+    // the step from the accepted point and, speculatively, the terms at the trial point (S, gradient, |gradient|^2,
+    // Hessian diagonal): ONE read-back per iteration
     rff_newton_step_kernel<<<1, 1024, 0, s>>>(om, g, h, F, radius, omt, out);
     if (int rc = rff_terms_async(ctx, d_Phi, F, N, m, sigma, omt, true, gt, ht, &sc, s)) return rc;
     PPBO_HIP_CHECK(ctx, hipMemcpyAsync(out + 3, sc, sizeof(double), hipMemcpyDeviceToDevice, s));
-    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(host, out, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (int rc = ppbo_dot_async(ctx, gt, gt, F, out + 4, s)) return rc;
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(host, out, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
     PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
     const double nrm = host[0], pred = host[1], Sn = host[3];
     gn = host[2];
+    gn_current = true;
     if (gn < gtol) break;                        // the accepted point is stationary: the trial is not used
     const double rho = (pred > 0.0) ? (Sn - S) / pred : -1.0;
     if (rho < 0.25) radius *= 0.25;
@@ -615,6 +620,7 @@ int ppbo_rff_omega_map(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, 
     if (rho > 0.15) {
       std::swap(om, omt); std::swap(g, gt); std::swap(h, ht);
       S = Sn;
+      gn = std::sqrt(host[4]);                   // |gradient| AT the accepted point (what h_gradnorm reports)
     }
     if (radius < 1e-14) { ++it; break; }
   }

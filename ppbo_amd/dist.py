@@ -50,12 +50,85 @@ def allgather_argmax(local_val: float, local_global_idx: int, device=None, group
     return combine_best(out[:, 0], out[:, 1].to(torch.int64))
 
 
+class ShardedSearch:
+    """The sharded candidate search with everything that can be set up once set up once: persistent device tensors
+    for this rank's 16-byte record and for the gathered records (no tensor is built from Python floats inside a
+    step, no host value is uploaded), the shard's row offset, and the choice of collective:
+
+      collective="torch"  torch.distributed.all_gather_into_tensor on the device records (backend nccl = RCCL), then
+                          ppbo_argmax_combine: one wavefront reduces the records, one 16-byte read-back;
+      collective="capi"   the ctx's own RCCL communicator behind the C-ABI: the whole step is ONE library call
+                          (ppbo_search_sharded: scoring, ncclAllGather, reduction, read-back on one stream, one host
+                          wait).  The 128-byte ncclUniqueId is created on rank 0 and broadcast through
+                          torch.distributed's store-backed object broadcast (any transport would do).
+
+    Per step the host waits exactly once, for the reduced record.  On host tensors (gloo: the CPU tests and the
+    shared-GPU test mode) the record is copied to the host and combine_best applies the same rule."""
+
+    def __init__(self, engine, post, Xc_shard, shard_offset: int, score, mustar=0.0, group=None, collective="torch",
+                 host_collective=False):
+        self.eng, self.post, self.Xc = engine, post, engine.dev(Xc_shard)
+        self.offset, self.score, self.mustar, self.group = int(shard_offset), score, float(mustar), group
+        self.rank, self.world = rank_world(group)
+        self.host = bool(host_collective)
+        if collective not in ("torch", "capi"):
+            raise ValueError("collective must be 'torch' or 'capi'")
+        self.collective = collective
+        self.record = engine.empty(2)
+        self.gathered = engine.empty(2 * self.world)
+        # the ctypes arguments of a step are built once (the model descriptor alone costs ~10 us of Python per call)
+        import ctypes as _C
+        from .engine import SCORE_MEAN, _ptr
+        self._md = engine._model(post, score != SCORE_MEAN)
+        self._md_ref = _C.byref(self._md)
+        self._xc_ptr, self._M = _ptr(self.Xc), int(self.Xc.shape[0])
+        self._bv, self._bi = _C.c_double(0.0), _C.c_int64(-1)
+        self._bv_ref, self._bi_ref = _C.byref(self._bv), _C.byref(self._bi)
+        self._rec_ptr = _ptr(self.record)
+        if self.host:
+            self.h_gathered = torch.empty(2 * self.world, dtype=torch.float64)
+        if collective == "capi" and not self.host and (self.world > 1 or dist.is_initialized()):
+            ids = [engine.dist_unique_id() if self.rank == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(ids, src=0, group=group)
+            engine.dist_init(ids[0], self.rank, self.world)
+            self._own_comm = True
+        else:
+            self._own_comm = False
+
+    def step(self):
+        """-> job-wide (best score, global row index), identical on every rank."""
+        eng = self.eng
+        if self.collective == "capi" and not self.host:
+            rc = eng.lib.ppbo_search_sharded(eng.ctx, self._md_ref, self._xc_ptr, self._M, int(self.score), self.mustar,
+                                             self.offset, self._bv_ref, self._bi_ref, eng._stream())
+            eng._check(rc, "ppbo_search_sharded")
+            return self._bv.value, self._bi.value
+        rc = eng.lib.ppbo_predict_record(eng.ctx, self._md_ref, self._xc_ptr, self._M, int(self.score), self.mustar,
+                                         self.offset, self._rec_ptr, eng._stream())
+        eng._check(rc, "ppbo_predict_record")
+        if self.world == 1 and not dist.is_initialized():
+            v, i = self.record.tolist()
+            return v, int(i)
+        if self.host:
+            dist.all_gather_into_tensor(self.h_gathered, self.record.cpu(), group=self.group)
+            out = self.h_gathered.view(self.world, 2)
+            return combine_best(out[:, 0], out[:, 1].to(torch.int64))
+        dist.all_gather_into_tensor(self.gathered, self.record, group=self.group)
+        return eng.argmax_combine(self.gathered)
+
+    def close(self):
+        if self._own_comm:
+            self.eng.dist_destroy()
+            self._own_comm = False
+
+
 def sharded_search(engine, post, Xc_shard, shard_offset: int, score, mustar=0.0, group=None):
-    """Score this rank's candidate rows on its GPU, then one all-gather for the argmax."""
-    out = engine.predict(post, Xc_shard, score=score, mustar=mustar, want_mu=False, want_var=False,
-                         want_score=False, want_best=True)
-    gidx = out["best_idx"] + shard_offset if out["best_idx"] >= 0 else -1
-    return allgather_argmax(out["best_val"], gidx, device=engine.device, group=group, engine=engine)
+    """Score this rank's candidate rows on its GPU, then one all-gather for the argmax (one-off form of
+    ShardedSearch: builds the persistent tensors, runs one step)."""
+    _, world = rank_world(group)
+    host = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "gloo"
+    return ShardedSearch(engine, post, Xc_shard, shard_offset, score, mustar, group, host_collective=host).step()
 
 
 def rank_world(group=None):

@@ -130,6 +130,39 @@ class Engine:
         self._check(rc, "ppbo_argmax_combine")
         return bv.value, bi.value
 
+    def dist_destroy(self):
+        self._check(self.lib.ppbo_dist_destroy(self.ctx), "ppbo_dist_destroy")
+
+    def argmax_allgather_record(self, record):
+        """record: device float64 [2] as written by predict_record -> job-wide (best value, global index) through the
+        ctx's RCCL communicator (ppbo_argmax_allgather_record: all-gather, reduction, one 16-byte read-back)."""
+        bv, bi = C.c_double(0.0), C.c_int64(-1)
+        rc = self.lib.ppbo_argmax_allgather_record(self.ctx, _ptr(record), C.byref(bv), C.byref(bi), self._stream())
+        self._check(rc, "ppbo_argmax_allgather_record")
+        return bv.value, bi.value
+
+    def predict_record(self, post, Xc, score=SCORE_MEAN, mustar=0.0, index_offset=0, out=None, kstar_fp32=False):
+        """One shard of a sharded search, enqueue only (ppbo_predict_record): out[2] (device) = (best score,
+        index_offset + first row index as a float64); nothing is read back, nothing synchronises."""
+        Xc = self.dev(Xc)
+        md = self._model(post, score != SCORE_MEAN, kstar_fp32)
+        rec = self.empty(2) if out is None else out
+        rc = self.lib.ppbo_predict_record(self.ctx, C.byref(md), _ptr(Xc), Xc.shape[0], int(score), float(mustar),
+                                          int(index_offset), _ptr(rec), self._stream())
+        self._check(rc, "ppbo_predict_record")
+        return rec
+
+    def search_sharded(self, post, Xc, score=SCORE_MEAN, mustar=0.0, index_offset=0, kstar_fp32=False):
+        """One whole sharded search step in ONE library call (ppbo_search_sharded): score this rank's rows, RCCL
+        all-gather of the 16-byte records (when dist_init has run on this ctx), reduction, one read-back."""
+        Xc = self.dev(Xc)
+        md = self._model(post, score != SCORE_MEAN, kstar_fp32)
+        bv, bi = C.c_double(0.0), C.c_int64(-1)
+        rc = self.lib.ppbo_search_sharded(self.ctx, C.byref(md), _ptr(Xc), Xc.shape[0], int(score), float(mustar),
+                                          int(index_offset), C.byref(bv), C.byref(bi), self._stream())
+        self._check(rc, "ppbo_search_sharded")
+        return bv.value, bi.value
+
     # ---- per-kernel event timing ---------------------------------------------
     def profile(self, on=True):
         self.lib.ppbo_profile_enable(self.ctx, int(on))
@@ -268,6 +301,8 @@ class Engine:
     def dgemv(self, A, x, trans=False, lower=False):
         A, x = self.dev(A), self.dev(x).reshape(-1)
         N = A.shape[0]
+        if A.dim() != 2 or A.shape[1] != N or x.numel() != N:
+            raise ValueError(f"dgemv: A is {tuple(A.shape)}, x has {x.numel()} entries (a square A and len(x) == N are required)")
         y = self.empty(N)
         rc = self.lib.ppbo_dgemv(self.ctx, int(trans), int(lower), N, _ptr(A), A.stride(0), _ptr(x), _ptr(y),
                                  self._stream())
@@ -322,7 +357,7 @@ class Engine:
         f0 = self.dev(f_init).reshape(-1)
         N = f0.numel()
         out = self.empty(N)
-        opts = _lib.FitOpts(float(gtol), int(maxiter), int(verbose), float(initial_radius), int(lbfgs_max_evals))
+        opts = _lib.FitOpts(float(gtol), int(maxiter), int(verbose), float(initial_radius), int(lbfgs_max_evals), 0)
         st = _lib.FitStats()
         if L is None:
             rc = self.lib.ppbo_fit_fmap(self.ctx, _ptr(Sigma_inv), N, m, float(sigma), _ptr(f0), C.byref(opts),

@@ -33,7 +33,7 @@ APPEND_REFRESH = 64            # incremental mode: bordered updates of Sigma^-1 
 
 
 class GPModel:
-    def __init__(self, PPBO_settings, engine=None, incremental=False):
+    def __init__(self, PPBO_settings, engine=None, incremental=False, fMAP_method=None):
         """incremental=True (not a reference feature): when update_data() has only appended one
         query's m+1 rows (feedback_processing.py:133-154), Sigma^-1 is bordered instead of refactorised
         (ppbo_pd_inverse_append) and f_MAP starts from the previous estimate padded with the previous posterior
@@ -50,7 +50,9 @@ class GPModel:
         # reference's optimum wherever T has one -- at sigma << sigma_f T has several local maxima and every local method,
         # SciPy's included, picks its own: DESIGN 5); anything else: the exact Newton trust region on f alone, which
         # follows SciPy trust-exact's iteration rules
-        self.fMAP_method = "whitened"
+        self.fMAP_method = fMAP_method if fMAP_method is not None else getattr(PPBO_settings, "fMAP_method", "whitened")
+        if self.fMAP_method not in ("whitened", "trust-region"):
+            raise ValueError("fMAP_method must be 'whitened' or 'trust-region'")
         self.fit_log = []            # one dict per update_fMAP trial: iterations, n_cholesky, warm, seconds
         s = PPBO_settings
         self.verbose = s.verbose
@@ -178,6 +180,21 @@ class GPModel:
     def update_Sigma(self, theta):
         self._dSigma = self.eng.gram(self._dX, theta, self.kernel.__name__, self.COVARIANCE_SHRINKAGE)
         self._invalidate("Sigma")
+        self._drop_stale_factor(theta)
+
+    def _drop_stale_factor(self, theta=None):
+        """The Cholesky factor kept from update_Sigma_inv belongs to ONE (X, theta): once Sigma has been rebuilt for
+        another theta or more rows, prior draws must not use it (an N_old x N_old factor against an
+        N-vector, or the factor of the previous theta).  The incremental append keys on _sinv_state itself and is
+        left alone: it checks theta and the row prefix before bordering."""
+        st = self._sinv_state
+        if self._dL is None:
+            return
+        th = None if theta is None else tuple(float(t) for t in theta)
+        if st is None or self._dL.shape[0] != self.N or (th is not None and st[1] != th):
+            self._dL_stale = True
+        else:
+            self._dL_stale = False
 
     def update_Sigma_inv(self, theta):
         th = tuple(float(t) for t in theta)
@@ -202,6 +219,7 @@ class GPModel:
                 (self._dSigma_inv, self._dL), self._dLinv = self.eng.pd_inverse_chol(self._dSigma), None
             self._sinv_state = (self.X.copy(), th, 0)
             self.n_full_inversions += 1
+        self._dL_stale = False
         self._invalidate("Sigma_inv", "Pinv")
 
     def set_theta(self):
@@ -400,7 +418,8 @@ class GPModel:
     def _draw_prior(self):
         """f ~ N(0, Sigma) for the random start (gp_model.py:374,381): L z with the device Cholesky
         factor and z from the global NumPy stream (the reference uses np.random.multivariate_normal)."""
-        if self._dL is not None:          # factor of the current Sigma, from update_Sigma_inv
+        if self._dL is not None and not self.__dict__.get("_dL_stale", False) and self._dL.shape[0] == self.N:
+            # factor of the current Sigma, from update_Sigma_inv
             return self.eng.dgemv(self._dL, np.random.standard_normal(self.N), lower=True)
         key = (self._dSigma.data_ptr(), getattr(self._dSigma, "_version", 0))
         cache = self.__dict__.get("_prior_chol")
@@ -451,7 +470,7 @@ class GPModel:
             if trials > 1:               # produced on a side stream, consumed on the caller's from here on
                 import torch
                 fm.record_stream(torch.cuda.current_stream(self.eng.device))
-            self.fit_log.append(dict(N=self.N, iterations=st["iterations"], n_cholesky=st["n_cholesky"],
+            self.fit_log.append(dict(N=self.N, method=self.fMAP_method, iterations=st["iterations"], n_cholesky=st["n_cholesky"],
                                      lbfgs_evals=st.get("lbfgs_evals", 0), lbfgs_status=st.get("lbfgs_status", -1),
                                      converged=st["converged"], warm=bool(warm), seconds=t_fit))
             if (self.fMAP_restart_on_stall and not st["converged"] and not approx_optimization

@@ -30,8 +30,16 @@ class PPBO_settings:
     def __init__(self, D, bounds, xi_acquisition_function, theta_initial=None, user_feedback_grid_size=100, m=25,
                  verbose=True, EI_EXR_mc_samples=150, EI_EXR_BO_maxiter=20, mustar_finding_trials=3,
                  kernel="SE_kernel", skip_computations_during_initialization=True,
-                 skip_xstaroptimization_during_initialization=False, alpha_grid_distribution="equispaced"):
+                 skip_xstaroptimization_during_initialization=False, alpha_grid_distribution="equispaced",
+                 fMAP_method="whitened"):
+        """fMAP_method (not a reference option): "whitened" = L-BFGS in z = L^-1 f finished by the trust
+        region (the default; O(N^2) per iteration), "trust-region" = the exact Newton trust region on f alone, which
+        follows SciPy trust-exact's iteration rules (the reference's optimiser class, src/gp_model.py:382-384) -- the
+        parity mode for flows that want the reference's basin behaviour at sigma << sigma_f."""
+        if fMAP_method not in ("whitened", "trust-region"):
+            raise ValueError("fMAP_method must be 'whitened' or 'trust-region'")
         vars(self).update(_FIXED)
+        self.fMAP_method = fMAP_method
         vars(self).update(
             D=D, original_bounds=bounds, verbose=verbose, kernel=kernel,
             user_feedback_grid_size=user_feedback_grid_size,

@@ -58,7 +58,8 @@ def test_gpus_1_line_is_well_formed():
     r = _run(["--steps", "3", "--warmup", "1", "--config", "c2", "--no-cpu-baseline", "--no-secondary"])
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["config"]["name"] == "c2"
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["name"] == "c2"
+    assert line["config"]["M_total"] == 16384 and line["ms_per_step_with_event_brackets"] > 0
     assert 0 < line["roofline"]["frac"] <= 1.0 and line["roofline"]["traffic"] is None
     assert line["roofline"]["dense_equivalent_tflops"] >= line["roofline"]["achieved"]
 
@@ -82,10 +83,28 @@ def test_two_ranks_sharing_one_gpu(scaling):
         assert line["config"]["M_total"] == 32768 and line["config"]["M_per_gpu"] == 16384
     assert 0 <= line["best"]["index"] < line["config"]["M_total"]
     assert abs(line["value"] - line["config"]["M_total"] * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-6 * line["value"]
-    assert "TEST MODE" in line["config"]["parallelism"]
+    assert "TEST MODE" in line["config"]["collective"]
     # every rank fitted the same model from the same inputs: alpha and G agree bit for bit (the replicas-instead-of-
     # broadcast assumption of DESIGN 6)
     assert line["replicated_fit_bitwise_equal"] is True
+    other = line["weak_scaling_leg" if scaling == "strong" else "strong_scaling_leg"]
+    assert other["M_total"] == (32768 if scaling == "strong" else 16384) and other["value"] > 0
+
+
+@pytest.mark.gpu
+def test_c3_defaults_to_strong_scaling_at_the_metrics_candidate_count():
+    """BASELINE's metric is quoted at a FIXED M = 65536 on 1/2/4/8 GPUs: `bench.py --gpus 2` with no other flag must
+    shard those 65536 candidates (32768 per rank) and report the strong-scaling rate as `value`; the weak leg (65536
+    per rank) rides along as a side key."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"],
+             {"PPBO_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["name"] == "c3" and line["n_gpus"] == 2
+    assert line["scaling"] == "strong" and line["config"]["M_total"] == 65536 and line["config"]["M_per_gpu"] == 32768
+    assert "strong" in line["config"]["parallelism"]
+    assert line["weak_scaling_leg"]["M_total"] == 131072 and line["weak_scaling_leg"]["M_per_gpu"] == 65536
+    assert 0 <= line["best"]["index"] < 65536
 
 
 @pytest.mark.gpu

@@ -161,6 +161,15 @@ def test_rff_omega_map_entry_point(eng):
     assert abs(S1 - S) <= 1e-12 * max(1.0, abs(S)) and np.linalg.norm(host(g1)) < 1e-6 and np.all(host(h1) < 0)
     om2, S2, gn2, it2 = eng.rff_omega_map(Phi, om, m, 0.3, maxiter=500, gtol=1e-6)
     assert it2 == 0 and np.array_equal(om2, om)
+    # stopped by the iteration cap: the reported |grad S| (and S) belong to the point that is RETURNED, not to the one
+    # the last step was computed from
+    start = rng.standard_normal(F)
+    for cap in (1, 2, 3, 5):
+        omk, Sk, gnk, itk = eng.rff_omega_map(Phi, start, m, 0.3, maxiter=cap, gtol=1e-12)
+        Sc, gc, _ = eng.rff_terms(Phi, omk, m, 0.3)
+        assert itk == cap
+        assert abs(Sc - Sk) <= 1e-12 * max(1.0, abs(Sk))
+        assert abs(np.linalg.norm(host(gc)) - gnk) <= 1e-10 * max(1.0, gnk), (cap, np.linalg.norm(host(gc)), gnk)
     with pytest.raises(RuntimeError):
         eng.rff_omega_map(Phi[:, :-1], rng.standard_normal(F), m, 0.3)
 

@@ -261,3 +261,59 @@ def test_loop_runs_under_every_strategy_and_grid(case):
     assert len(gp.theta) == 3 and all(np.isfinite(gp.theta)) and gp.theta[0] > 0
     if incremental:
         assert gp.n_appends >= 1
+
+
+def test_prior_draw_never_uses_a_stale_factor(golden):
+    """GPModel keeps the Cholesky factor of Sigma from update_Sigma_inv for its prior draws
+    (src/gp_model.py:374,381); after update_Sigma(theta') or after N grew -- and before the next update_Sigma_inv --
+    that factor belongs to another matrix: the draw must come from the CURRENT Sigma."""
+    g = golden("smoke")
+    gp, st = _model(g)
+    gp.set_theta()
+    gp.update_Sigma(gp.theta)
+    gp.update_Sigma_inv(gp.theta)
+
+    def draw():
+        np.random.seed(5)
+        z = np.random.standard_normal(gp.N)
+        np.random.seed(5)
+        return gp._draw_prior().cpu().numpy(), z
+
+    f, z = draw()
+    assert np.abs(f - np.linalg.cholesky(gp.Sigma) @ z).max() <= 1e-10
+    th2 = [gp.theta[0], 2.0 * gp.theta[1], 0.5 * gp.theta[2]]
+    gp.update_Sigma(th2)                                 # no update_Sigma_inv: the kept factor is the old theta's
+    f2, z2 = draw()
+    assert np.abs(f2 - np.linalg.cholesky(gp.Sigma) @ z2).max() <= 1e-10
+    assert np.abs(f2 - f).max() > 1e-3
+    gp.update_Sigma_inv(th2)                             # the factor is current again and is used again
+    f3, _ = draw()
+    assert np.abs(f3 - f2).max() <= 1e-10
+    with pytest.raises(ValueError):
+        gp.eng.dgemv(gp._dL, np.zeros(gp.N + 3), lower=True)
+
+
+def test_fmap_method_is_a_setting(golden):
+    from ppbo_amd.gp_model import GPModel
+    from ppbo_amd.ppbo_settings import PPBO_settings
+    g = golden("smoke")
+    for method in ("whitened", "trust-region"):
+        st = PPBO_settings(D=int(g["D"]), bounds=tuple(map(tuple, g["bounds"])), xi_acquisition_function="PCD",
+                           theta_initial=list(g["theta"]), m=int(g["m"]), verbose=False, kernel=str(g["kernel"]),
+                           fMAP_method=method)
+        gp = GPModel(st)
+        assert gp.fMAP_method == method
+        np.random.seed(0)
+        gp.update_feedback_processing_object(g["X_obs"])
+        gp.FP.X = g["X"].copy()
+        gp.update_data()
+        gp.set_theta()
+        gp.update_Sigma(gp.theta)
+        gp.update_Sigma_inv(gp.theta)
+        gp.fMAP = g["f_init"].copy()
+        gp.update_fMAP(random_initial_vector=False)
+        assert gp.fit_log[-1]["method"] == method
+        assert (gp.fit_log[-1]["lbfgs_evals"] > 0) == (method == "whitened")
+        assert np.abs(gp.fMAP - g["fMAP"]).max() <= 5e-5 * np.abs(g["fMAP"]).max()
+    with pytest.raises(ValueError):
+        PPBO_settings(D=2, bounds=((0, 1),) * 2, xi_acquisition_function="PCD", fMAP_method="newton")

@@ -101,7 +101,7 @@ def build_design(gp_mod, settings_mod, cfg):
         rows.append(np.concatenate([a * xi + x, xi, [a]]))
     X_obs = np.array(rows)
     st = settings_mod.PPBO_settings(D=D, bounds=bounds, xi_acquisition_function="PCD",
-                                    theta_initial=list(cfg["theta"]), m=M_PSEUDO, verbose=False,
+                                    theta_initial=list(cfg["theta"]), m=cfg.get("m", M_PSEUDO), verbose=False,
                                     kernel=cfg["kernel"])
     gp = gp_mod.GPModel(st)
     gp.update_feedback_processing_object(X_obs)

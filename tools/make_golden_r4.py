@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Round-4 golden vectors, produced by running the REFERENCE ITSELF (build container only; the in-memory shims of
+tools/make_golden.py, nothing copied).
+
+  multistart_<cfg>.npz   cfg in {c2, c4}: the regime sigma << sigma_f where T has several strict local maxima
+      (DESIGN section 5).  For K prior draws f_init[k] ~ N(0, Sigma) (numpy default_rng(100 + k), Cholesky method)
+      the reference's own update_fMAP (src/gp_model.py:354-389: SciPy trust-exact, default gtol 1e-4, ONE trial per
+      start, the global-RNG draw patched to return the stored start) is run and its result recorded:
+          f_init[K,N], fMAP[K,N], T[K] (the reference's T at its result), gradnorm[K] (|T_grad|_2 there),
+          nit[K], seconds[K]
+      plus best_k = the start the reference's "keep the lowest -T" rule (:385-387) would keep over these K trials.
+      X / theta / m are those of <cfg>.npz (asserted equal).
+      cfg in {mm_se, mm_rq}: two small models (own designs, same recipe) at sigma / sigma_f ~ 1e-3 where the reference's
+      own runs end in DIFFERENT local maxima depending on the start: what any local method can be held to there.
+
+usage: python tools/make_golden_r4.py multistart c2 [K]
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_golden as mg  # noqa: E402
+
+OUT = mg.OUT
+# small models in the multimodal regime (hyper-parameters of two cases of tests/probes/fit_fuzz.py where SciPy's
+# trust-exact itself ends in different maxima from different prior draws)
+mg.CONFIGS["mm_se"] = dict(D=9, n_q=4, m=25, theta=[0.0014, 0.4239, 1.5365], kernel="SE_kernel", F=0, ev=False, omap=False)
+mg.CONFIGS["mm_rq"] = dict(D=2, n_q=10, m=29, theta=[0.002, 0.744, 0.8929], kernel="RQ_kernel", F=0, ev=False, omap=False)
+
+
+def multistart(name, K=8):
+    import gp_model as ref_gp
+    import ppbo_settings as ref_settings
+    gp, st, _ = mg.build_design(ref_gp, ref_settings, mg.CONFIGS[name])
+    if os.path.exists(os.path.join(OUT, f"{name}.npz")):
+        assert np.array_equal(np.asarray(gp.X), np.load(os.path.join(OUT, f"{name}.npz"))["X"])
+    gp.set_theta()
+    gp.update_Sigma(gp.theta)
+    gp.update_Sigma_inv(gp.theta)
+    N = gp.N
+    Sig = np.asarray(gp.Sigma)
+    f_inits, fmaps, Ts, gns, secs = [], [], [], [], []
+    _mvn = np.random.multivariate_normal
+    path = os.path.join(OUT, f"multistart_{name}.npz")
+    for k in range(K):
+        f0 = np.random.default_rng(100 + k).multivariate_normal(np.zeros(N), Sig, method="cholesky")
+        np.random.multivariate_normal = lambda mean, cov, *a, f0=f0, **kw: f0.copy()
+        t0 = time.time()
+        try:
+            gp.fMAP = None
+            gp.update_fMAP(fmap_finding_trials=1)
+        finally:
+            np.random.multivariate_normal = _mvn
+        dt = time.time() - t0
+        f = np.asarray(gp.fMAP).ravel().copy()
+        Tv = float(gp.T(f, gp.theta))
+        gn = float(np.linalg.norm(gp.T_grad(f, gp.theta)))
+        f_inits.append(f0)
+        fmaps.append(f)
+        Ts.append(Tv)
+        gns.append(gn)
+        secs.append(dt)
+        print(f"[multistart_{name}] start {k}: T = {Tv:.10f}  |grad| = {gn:.3e}  {dt:.1f}s", flush=True)
+        # written after every start so a long run can be cut short without losing what is done
+        np.savez_compressed(path, name=name, X=np.asarray(gp.X), theta=np.asarray(gp.theta, dtype=float), m=gp.m,
+                            kernel=mg.CONFIGS[name]["kernel"],
+                            f_init=np.stack(f_inits), fMAP=np.stack(fmaps), T=np.array(Ts), gradnorm=np.array(gns),
+                            seconds=np.array(secs), best_k=int(np.argmax(Ts)))
+    print(f"[multistart_{name}] wrote {path} ({os.path.getsize(path) / 1e3:.0f} kB); best start {int(np.argmax(Ts))}")
+
+
+if __name__ == "__main__":
+    mg.install_shims()
+    args = sys.argv[1:]
+    if len(args) < 2 or args[0] != "multistart":
+        sys.exit(__doc__)
+    multistart(args[1], int(args[2]) if len(args) > 2 else 8)
