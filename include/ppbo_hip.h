@@ -165,6 +165,9 @@ typedef struct ppbo_fit_opts {
                             * ppbo_fit_fmap_whitened for its finishing phase): a step whose predicted decrease is below
                             * the rounding noise of the objective difference is accepted when it lowers |grad| --
                             * next to the optimum actual / predicted is a random number */
+  int start_is_whitened;   /* ppbo_gp_fit only: d_f_init holds z0 (e.g. the standard-normal draw itself) and the search
+                            * starts at f = L z0 -- the reference's prior draw N(0, Sigma) (src/gp_model.py:374,381)
+                            * without forming it and whitening it again */
 } ppbo_fit_opts;
 typedef struct ppbo_fit_stats {
   int iterations;   /* outer trust-region iterations */
@@ -195,6 +198,26 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
 int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m,
                            double sigma, const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
                            ppbo_fit_stats* h_stats, void* stream);
+
+/* ---- a-1 ... a-8 + the posterior in ONE call: what GPModel.update_model does between update_data and mu_star ----
+ * replaces update_Sigma + update_Sigma_inv + update_fMAP (one trial from d_f_init) + create_Lambda + the posterior
+ * covariance (src/gp_model.py:91-117) -- i.e. ppbo_gram, ppbo_pd_inverse_ex, ppbo_fit_fmap_whitened and
+ * ppbo_posterior behind one entry, with what that allows:
+ *   - Sigma^-1 = L^-T L^-1 is formed on the ctx's side stream while the whitened search (which needs only L and, for
+ *     z0, L^-1) already runs on `stream`; the search asks for |grad_f T| (which needs Sigma^-1) from its fifth
+ *     evaluation on, behind an event;
+ *   - no host wait between the phases: the two factorizations' info words and the search's state are read once, at
+ *     the end (the search itself is steered through a host-mapped progress word, not through stream synchronisation).
+ * Outputs (device, caller-owned): d_Sigma [N,N] (NULL to skip), d_Sigma_inv [N,N], d_L [N,N] (Cholesky factor of
+ * Sigma, lower triangle valid), d_Linv [N,N] (NULL: kept in a workspace), d_fMAP [N], and -- all four or none --
+ * d_alpha, d_lam_diag, d_lam_off [N], d_G [N,N] as ppbo_posterior defines them.
+ * Returns PPBO_ERR_NOT_PD with *h_info = 1 when Sigma is not positive definite, *h_info = 2 when Sigma^-1 - Lambda_MAP
+ * is not (f_MAP and the factors of Sigma are valid then; the reference prints its '---!!!---' line and keeps the
+ * previous posterior, src/gp_model.py:118-120). */
+int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, const double theta[3], double shrink,
+                int m, const double* d_f_init, const ppbo_fit_opts* opts, double* d_Sigma, double* d_Sigma_inv,
+                double* d_L, double* d_Linv, double* d_fMAP, double* d_alpha, double* d_lam_diag, double* d_lam_off,
+                double* d_G, ppbo_fit_stats* h_stats, int* h_info, void* stream);
 
 /* T(f) and grad T(f) for a given f (src/gp_model.py:221-240); h_T / d_grad may be NULL */
 int ppbo_T_and_grad(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_f, int N, int m,

@@ -22,7 +22,8 @@ SCORE_MEAN, SCORE_POINTWISE_EI, SCORE_VARIANCE = 0, 1, 2
 
 class FitOpts(C.Structure):
     _fields_ = [("gtol", C.c_double), ("maxiter", C.c_int), ("verbose", C.c_int), ("initial_radius", C.c_double),
-                ("lbfgs_max_evals", C.c_int), ("judge_by_gradient_below_noise", C.c_int)]
+                ("lbfgs_max_evals", C.c_int), ("judge_by_gradient_below_noise", C.c_int),
+                ("start_is_whitened", C.c_int)]
 
 
 class FitStats(C.Structure):
@@ -63,6 +64,8 @@ SIGNATURES = {
     "ppbo_sum_phi": [_vp, _vp, _i, _i, _d, _i, _vp, _vp],
     "ppbo_fit_fmap": [_vp, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
     "ppbo_fit_fmap_whitened": [_vp, _vp, _i, _vp, _i, _i, _d, _vp, C.POINTER(FitOpts), _vp, C.POINTER(FitStats), _vp],
+    "ppbo_gp_fit": [_vp, _i, _vp, _i, _i, _dp3, _d, _i, _vp, C.POINTER(FitOpts), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                    C.POINTER(FitStats), C.POINTER(_i), _vp],
     "ppbo_T_and_grad": [_vp, _vp, _vp, _i, _i, _d, C.POINTER(_d), _vp, _vp],
     "ppbo_posterior": [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_predict": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _vp, _vp, _vp, C.POINTER(_d), C.POINTER(_i64), _vp],

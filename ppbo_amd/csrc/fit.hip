@@ -12,6 +12,8 @@
 // More-Sorensen iteration on lam (Conn/Gould/Toint Alg. 7.3.4 without hard-case
 // refinement): each trial lam = one device Cholesky (potrf) + triangular inverse
 // (trtri) + three GEMVs.  The host loop only reads a handful of scalars per trial.
+#include <chrono>
+
 #include "linalg.h"
 
 namespace {
@@ -322,6 +324,8 @@ struct WhState {
   int status;      // 0 running, 1 converged (|grad_f| < gtol), 2 stagnated at the rounding floor, 3 line search
                    // failed along steepest descent, 4 non-finite objective at the start, 5 evaluation budget spent
   int evals, iters, hist, head, first, ls, stall, need_gf, max_evals;
+  int gf_avail;    // 0 while Sigma^-1 is still being formed on the side stream (ppbo_gp_fit): |grad_f| cannot be asked for yet
+  int pad_;
   double phi, dphi, alpha, gz2, gf2, gate, gtol2, gzbest;
   double B[LB_NB * LB_NB];
   double delta[LB_NB];   // coefficients (over the basis) of the direction behind the current trial point
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const double* __restric
 }
 
 __global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ st, const double* __restrict__ rowsq,
-                                                          int N, double gtol, int max_evals) {
+                                                          int N, double gtol, int max_evals, int gf_avail) {
   __shared__ double sh[LB_T / 64];
   double s = 0.0;
   for (int i = threadIdx.x; i < N; i += LB_T) s += rowsq[i];
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ 
     double t = 0.0;
     for (int w = 0; w < LB_T / 64; ++w) t += sh[w];
     st->status = 0; st->evals = 0; st->iters = 0; st->hist = 0; st->head = 0; st->first = 1; st->ls = 0;
-    st->stall = 0; st->need_gf = 0; st->max_evals = max_evals;
+    st->stall = 0; st->need_gf = 0; st->max_evals = max_evals; st->gf_avail = gf_avail; st->pad_ = 0;
     st->phi = 0.0; st->dphi = 0.0; st->alpha = 0.0; st->gz2 = 0.0; st->gf2 = -1.0;
     st->gate = gtol * sqrt(t);          // |grad_f| < gtol needs |grad_z| < gtol |L|_F
     st->gtol2 = gtol * gtol;
@@ -398,9 +402,27 @@ __device__ __forceinline__ void lb_block_sum(double (&v)[K], double* __restrict_
 // the start and written once at the end -- a thread that loads, computes, stores and loads again from global memory
 // pays ~1 us per dependent access, which made the first version of this function take 25-45 us.
 struct WhHead {
-  int status, evals, iters, hist, head, first, ls, stall, need_gf, max_evals;
+  int status, evals, iters, hist, head, first, ls, stall, need_gf, max_evals, gf_avail, pad_;
   double phi, dphi, alpha, gz2, gf2, gate, gtol2, gzbest;
 };
+// Progress of the search as the host sees it: the step kernel stores (status << 32 | evals) into host-mapped memory
+// after every judgement (system scope), and the scalar head once the search has ended (before the final progress
+// word).  The host polls the word between enqueues: it never runs more than a few slots ahead of the device, stops
+// enqueueing as soon as the search is over, and needs neither a device-to-host copy nor a stream synchronisation.
+struct WhProgress {
+  unsigned long long* word;   // device view of the host-mapped progress word
+  int* head;                  // device view of the host-mapped copy of WhHead (written when status != 0)
+};
+__device__ __forceinline__ void wh_publish(const WhProgress& pr, const WhHead& hs) {
+  if (!pr.word) return;
+  if (hs.status != 0) {
+    constexpr int HWI = (int)(sizeof(WhHead) / 4);
+    const int* src = reinterpret_cast<const int*>(&hs);
+    for (int k = 0; k < HWI; ++k) pr.head[k] = src[k];
+  }
+  __hip_atomic_store(pr.word, ((unsigned long long)(unsigned)hs.status << 32) | (unsigned)hs.evals, __ATOMIC_RELEASE,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
 static_assert(sizeof(WhHead) == offsetof(WhState, B), "WhHead mirrors the head of WhState");
 
 // One judgement of the trial point zt (its products u = L^T beta(L zt), v = Sigma^-1 L zt and the per-query
@@ -416,7 +438,8 @@ template <int NT>
 __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int m, int n_q, double* __restrict__ z,
                                            double* __restrict__ zt, double* __restrict__ d, const double* u,
                                            const double* v, const double* beta, const double* tq,
-                                           double* __restrict__ basis, long long* dbg = nullptr) {
+                                           double* __restrict__ basis, long long* dbg = nullptr,
+                                           WhProgress prog = WhProgress{nullptr, nullptr}) {
   // verbose >= 2: wall_clock64 stamps of the phases of evaluations 3..9 (tools/fit_whitened.py <cfg> <gtol> 2)
 #define LSTAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = wall_clock64(); } while (0)
   constexpr int HW = (int)(sizeof(WhHead) / 4);
@@ -529,6 +552,7 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
       if (tid < LB_NB) st->delta[tid] = (tid == 2 * LB_H) ? -1.0 : 0.0;
     }
     if (tid < HW) reinterpret_cast<int*>(st)[tid] = reinterpret_cast<const int*>(&hs)[tid];
+    if (tid == 0) wh_publish(prog, hs);
     return;
   }
   // ---- accepted: the Gram matrix of the new basis, by algebra
@@ -575,7 +599,7 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
     else if (hs.stall >= 3) { hs.status = 2; stop = 1; }
     else if (hs.evals >= hs.max_evals) { hs.status = 5; stop = 1; }
     else if (!(gz2 > 0.0)) { hs.status = isfinite(gz2) ? 1 : 4; stop = 1; }
-    hs.need_gf = sqrt(gz2) < hs.gate;
+    hs.need_gf = hs.gf_avail && sqrt(gz2) < hs.gate;
     hs.hist = hist; hs.head = head; hs.first = 0;
     act[3] = stop;
   }
@@ -630,6 +654,9 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
   if (tid < HW) reinterpret_cast<int*>(st)[tid] = reinterpret_cast<const int*>(&hs)[tid];
   // ---- pass 2: commit the point, the gradient and the pair; next direction and trial point
   const int stop = act[3];
+  // a search that goes on is announced BEFORE pass 2 (the host may enqueue the next slot meanwhile); one that has
+  // ended only after z has been committed: the host reads z (through f = L z) as soon as it sees the end
+  if (tid == 0 && !stop) wh_publish(prog, hs);
   const double an = shs[0];
   for (int i = tid; i < N; i += NT) {
     const double zi = zt[i], gt = zi - u[i];
@@ -656,6 +683,11 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
     }
   }
   LSTAMP(8);
+  if (stop) {
+    __syncthreads();
+    __threadfence();
+    if (tid == 0) wh_publish(prog, hs);
+  }
 #undef LSTAMP
 }
 
@@ -665,9 +697,11 @@ __global__ __launch_bounds__(LB_T) void lbfgs_step_kernel(WhState* __restrict__ 
                                                           const double* __restrict__ v,
                                                           const double* __restrict__ beta,
                                                           const double* __restrict__ tq, double* __restrict__ basis,
-                                                          long long* dbg) {
-  lbfgs_step<LB_T>(st, N, m, n_q, z, zt, d, u, v, beta, tq, basis, dbg);
+                                                          long long* dbg, WhProgress prog) {
+  lbfgs_step<LB_T>(st, N, m, n_q, z, zt, d, u, v, beta, tq, basis, dbg, prog);
 }
+
+__global__ void set_int_flag_kernel(int* p, int v) { *p = v; }
 
 // beta(f) and u = L^T beta in ONE launch: every workgroup rebuilds beta for itself in LDS (N exponentials -- cheaper
 // than a dependent launch), then each wavefront owns one row of the row-major copy U of L^T (zero left of the
@@ -1107,14 +1141,30 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
   return 0;
 }
 
-int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m,
-                           double sigma, const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
-                           ppbo_fit_stats* h_stats, void* stream) {
-  PPBO_ENTER(ctx);
-  PPBO_REQUIRE(ctx, d_L && d_Sigma_inv && d_f_init && d_fMAP, "null pointer");
-  PPBO_REQUIRE(ctx, N > 0 && ldl >= N && m >= 1 && sigma > 0, "sizes");
-  PPBO_REQUIRE(ctx, N % (m + 1) == 0, "N must be n_q*(m+1)");
-  hipStream_t s = (hipStream_t)stream;
+}  // extern "C"
+
+namespace {
+
+// How far the host may run ahead of the device with its slot enqueues: the host needs ~25 us per slot, the device
+// ~45 us, so two slots of lead keep the device fed; whatever is queued beyond the slot that ends the search is a
+// handful of gated no-op launches (the first version enqueued 4, 8, 16, ... slots per read-back: up to 8 dead slots
+// = 48 launches and three stream synchronisations per fit).
+constexpr int WH_AHEAD = 3;
+
+struct WhitenedExtras {
+  const double* d_Linv = nullptr;    // when given: z0 = L^-1 f_init by one triangular product (else L^T (Sigma^-1 f_init))
+  bool start_is_z = false;           // d_f_init IS z0
+  hipEvent_t sinv_ready = nullptr;   // when given: Sigma^-1 is still being formed on another stream; the search starts
+                                     // without it (|grad_f| is not asked for: gf_avail = 0) and waits for the event in
+                                     // front of slot WH_SINV_SLOT, far enough in for the GEMM (on half of the CUs) to have finished
+  bool* waited = nullptr;            // set once the stream has been made to wait for sinv_ready
+  bool sync_at_end = true;           // false: d_fMAP is only enqueued (the caller synchronises later)
+};
+constexpr int WH_SINV_SLOT = 8;
+
+int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m, double sigma,
+                    const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP, ppbo_fit_stats* h_stats,
+                    hipStream_t s, const WhitenedExtras& ex) {
   const double gtol = (opts && opts->gtol > 0) ? opts->gtol : 1e-4;
   const int verbose = opts ? opts->verbose : 0;
   const int max_evals = (opts && opts->lbfgs_max_evals > 0) ? opts->lbfgs_max_evals : 4000;
@@ -1129,16 +1179,27 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
   double* z = basis + (size_t)LB_NB * N;
   double *zt = z + N, *dd = zt + N, *u = dd + N, *v = u + N, *beta = v + N, *ft = beta + N, *rowsq = ft + N;
   double* tq = rowsq + N;
-  WhState* hst = (WhState*)ppbo_pinned(ctx, sizeof(WhState) + 64 * sizeof(double));
-  if (!hst) return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "pinned staging");
-  const size_t head_bytes = offsetof(WhState, B);
+  // host-mapped progress word + head copy (the ctx's result record block: doubles [4, 4 + 16) hold the head, [24] the word)
+  PpboHostRecord hr;
+  if (int rc = ppbo_host_record(ctx, &hr)) return rc;
+  static_assert(sizeof(WhHead) <= 16 * sizeof(double), "head copy fits its slot of the host-mapped block");
+  WhProgress prog{reinterpret_cast<unsigned long long*>(hr.d_rec + 24), reinterpret_cast<int*>(hr.d_rec + 4)};
+  volatile unsigned long long* h_word = reinterpret_cast<volatile unsigned long long*>(const_cast<double*>(hr.h_rec) + 24);
+  const WhHead* h_head = reinterpret_cast<const WhHead*>(const_cast<double*>(hr.h_rec) + 4);
+  *h_word = 0;                          // nothing of this ctx is in flight that could write it (one search per ctx at a time)
   PPBO_HIP_CHECK(ctx, hipMemsetAsync(base, 0, (st_doubles + (size_t)LB_NB * N) * sizeof(double), s));
   row_sqnorm_kernel<<<(N + 3) / 4, 256, 0, s>>>(d_L, N, ldl, rowsq);
-  lbfgs_init_kernel<<<1, LB_T, 0, s>>>(st, rowsq, N, gtol, max_evals);
+  lbfgs_init_kernel<<<1, LB_T, 0, s>>>(st, rowsq, N, gtol, max_evals, ex.sinv_ready ? 0 : 1);
   PPBO_LAUNCH_CHECK(ctx);
-  // z0 = L^-1 f_init = L^T (Sigma^-1 f_init)
-  if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, d_f_init, v, 0, 0, s)) return rc;
-  if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, v, zt, 1, 1, s)) return rc;
+  if (ex.start_is_z) {
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(zt, d_f_init, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+  } else if (ex.d_Linv) {
+    if (int rc = ppbo_gemv_async(ctx, ex.d_Linv, N, N, d_f_init, zt, 0, 1, s)) return rc;     // z0 = L^-1 f_init
+  } else {
+    // z0 = L^-1 f_init = L^T (Sigma^-1 f_init)
+    if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, d_f_init, v, 0, 0, s)) return rc;
+    if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, v, zt, 1, 1, s)) return rc;
+  }
   PpboGate run; run.skip_if_nonzero = &st->status;
   PpboGate run_gf = run; run_gf.skip_if_zero = &st->need_gf;
   long long* dbg = nullptr;
@@ -1168,22 +1229,53 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
       if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, beta, u, 1, 1, s, run)) return rc;               // u = L^T beta
     }
     if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, ft, v, 0, 0, s, run_gf)) return rc;          // v = Sigma^-1 f
-    lbfgs_step_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, v, beta, tq, basis, dbg);
+    lbfgs_step_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, v, beta, tq, basis, dbg, prog);
     return 0;
   };
-  int batch = 4;
-  for (;;) {
-    for (int k = 0; k < batch; ++k)
+  auto wait_sinv = [&]() -> int {
+    if (!ex.sinv_ready || (ex.waited && *ex.waited)) return 0;
+    PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(s, ex.sinv_ready, 0));
+    set_int_flag_kernel<<<1, 1, 0, s>>>(&st->gf_avail, 1);
+    if (ex.waited) *ex.waited = true;
+    return 0;
+  };
+  int enq = 0, status = 0, evals = 0;
+  bool synced = false;
+  auto t_last = std::chrono::steady_clock::now();
+  unsigned long long last_word = 0;
+  for (unsigned spins = 0;; ++spins) {
+    const unsigned long long w = *h_word;
+    status = (int)(w >> 32);
+    evals = (int)(w & 0xffffffffu);
+    if (status != 0) break;
+    if (enq - evals < WH_AHEAD && enq < max_evals + WH_AHEAD) {
+      if (enq == WH_SINV_SLOT)
+        if (int rc = wait_sinv()) return rc;
       if (int rc = enqueue_slot()) return rc;
-    PPBO_LAUNCH_CHECK(ctx);
-    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(hst, st, head_bytes, hipMemcpyDeviceToHost, s));
-    PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
-    if (verbose)
-      printf("[ppbo_fit whitened] evals %d iters %d phi %.12e |grad_z| %.3e |grad_f| %.3e status %d\n", hst->evals,
-             hst->iters, hst->phi, std::sqrt(hst->gz2), hst->gf2 >= 0 ? std::sqrt(hst->gf2) : -1.0, hst->status);
-    if (hst->status != 0) break;
-    if (batch < 16) batch *= 2;
+      ++enq;
+      continue;
+    }
+    __builtin_ia32_pause();
+    if (w != last_word) { last_word = w; t_last = std::chrono::steady_clock::now(); }
+    else if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t_last > std::chrono::seconds(5)) {
+      // no progress word for seconds: let the runtime wait and read the state the ordinary way
+      PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+      synced = true;
+      break;
+    }
   }
+  PPBO_LAUNCH_CHECK(ctx);
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  WhHead head;
+  if (synced && (int)(*h_word >> 32) == 0) {
+    PPBO_HIP_CHECK(ctx, hipMemcpy(&head, st, sizeof(WhHead), hipMemcpyDeviceToHost));
+    if (head.status == 0) return ppbo_set_error(ctx, (int)hipErrorUnknown, "the whitened search made no progress");
+  } else {
+    std::memcpy(&head, h_head, sizeof(WhHead));
+  }
+  if (verbose)
+    printf("[ppbo_fit whitened] evals %d iters %d phi %.12e |grad_z| %.3e |grad_f| %.3e status %d (slots enqueued %d)\n",
+           head.evals, head.iters, head.phi, std::sqrt(head.gz2), head.gf2 >= 0 ? std::sqrt(head.gf2) : -1.0, head.status, enq);
   if (dbg) {
     long long h[256];
     (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
@@ -1196,19 +1288,35 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
              (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01);
     }
   }
-  const int lb_status = hst->status, lb_iters = hst->iters, lb_evals = hst->evals;
+  const int lb_status = head.status, lb_iters = head.iters, lb_evals = head.evals;
   if (lb_status == 4) {
     // the start vector has no finite objective in whitened form: leave everything to the trust region
-    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(d_fMAP, d_f_init, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (ex.start_is_z) {
+      if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, d_f_init, d_fMAP, 0, 1, s)) return rc;             // f = L z0
+    } else {
+      PPBO_HIP_CHECK(ctx, hipMemcpyAsync(d_fMAP, d_f_init, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
   } else {
     if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, z, d_fMAP, 0, 1, s)) return rc;                      // f = L z
   }
-  // finisher: the exact trust-region Newton from there (no iteration at all when |grad_f| < gtol already holds)
+  if (lb_status == 1 && head.gf2 >= 0.0 && head.gf2 < gtol * gtol) {
+    // ended on the reference's own rule |grad_f T| < gtol, evaluated at the accepted point: nothing is left for the
+    // finisher to do (it used to re-evaluate the point and synchronise twice to find that out: ~0.1 ms)
+    if (h_stats) {
+      h_stats->iterations = 0; h_stats->n_cholesky = 0; h_stats->converged = 1;
+      h_stats->T = -head.phi; h_stats->gradnorm = std::sqrt(head.gf2);
+      h_stats->lbfgs_iterations = lb_iters; h_stats->lbfgs_evals = lb_evals; h_stats->lbfgs_status = lb_status;
+    }
+    if (ex.sync_at_end) PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    return 0;
+  }
+  // finisher: the exact trust-region Newton from there
+  if (int rc = wait_sinv()) return rc;
   ppbo_fit_stats tr{};
   ppbo_fit_opts fin{};
   if (opts) fin = *opts;
   fin.judge_by_gradient_below_noise = 1;
-  const int rc = ppbo_fit_fmap(ctx, d_Sigma_inv, N, m, sigma, d_fMAP, &fin, d_fMAP, &tr, stream);
+  const int rc = ppbo_fit_fmap(ctx, d_Sigma_inv, N, m, sigma, d_fMAP, &fin, d_fMAP, &tr, (void*)s);
   if (h_stats) {
     *h_stats = tr;
     h_stats->lbfgs_iterations = lb_iters;
@@ -1218,27 +1326,21 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
   return rc;
 }
 
-int ppbo_posterior(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fMAP, int N, int m, double sigma,
-                   double* d_alpha, double* d_lam_diag, double* d_lam_off, double* d_G, double* d_P, int* h_info,
-                   void* stream) {
-  PPBO_ENTER(ctx);
-  PPBO_REQUIRE(ctx, d_Sigma_inv && d_fMAP && d_alpha && d_lam_diag && d_lam_off && d_G, "null pointer");
-  PPBO_REQUIRE(ctx, N > 0 && m >= 1 && sigma > 0 && N % (m + 1) == 0, "sizes");
-  hipStream_t s = (hipStream_t)stream;
+// Lambda_MAP, alpha, B = Sigma^-1 - Lambda = L_B L_B^T, R = L_B^-1, G = R Lambda (and P = R^T R) -- everything enqueued,
+// the factorization's info word left on the device (d_info)
+int posterior_async(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fMAP, int N, int m, double sigma,
+                    double* d_alpha, double* d_lam_diag, double* d_lam_off, double* d_G, double* d_P, int* d_info,
+                    hipStream_t s) {
   const int mblk = m + 1, n_q = N / mblk;
   const size_t nn = (size_t)N * N;
   double* H = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG, 2 * nn * sizeof(double));
   if (!H) return (int)hipErrorOutOfMemory;
   double* R = H + nn;
-  if (h_info) *h_info = 0;
   if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, d_fMAP, d_alpha, 0, 0, s)) return rc;
   laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(d_fMAP, N, mblk, n_q, sigma, nullptr, nullptr, d_lam_diag, d_lam_off);
   form_shifted_kernel<<<N, 256, 0, s>>>(d_Sigma_inv, N, mblk, d_lam_diag, d_lam_off, 0.0, H, nullptr);
   PPBO_LAUNCH_CHECK(ctx);
-  int info = 0;
-  const int rc = ppbo_potrf(ctx, H, N, N, &info, stream);
-  if (h_info) *h_info = info;
-  if (rc) return rc;
+  if (int rc = ppbo_potrf_async(ctx, H, N, N, d_info, s)) return rc;
   if (int rc2 = ppbo_trtri_async(ctx, H, N, N, R, N, s)) return rc2;
   g_build_kernel<<<dim3((N + 255) / 256, N), 256, 0, s>>>(R, N, mblk, d_lam_diag, d_lam_off, d_G);
   PPBO_LAUNCH_CHECK(ctx);
@@ -1248,6 +1350,117 @@ int ppbo_posterior(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fMA
     g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0; g.klo_mode = 1; g.tri_block = 1;
     if (int rc3 = ppbo_gemm_launch(ctx, g, 1, 0, s)) return rc3;
   }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m,
+                           double sigma, const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
+                           ppbo_fit_stats* h_stats, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_L && d_Sigma_inv && d_f_init && d_fMAP, "null pointer");
+  PPBO_REQUIRE(ctx, N > 0 && ldl >= N && m >= 1 && sigma > 0, "sizes");
+  PPBO_REQUIRE(ctx, N % (m + 1) == 0, "N must be n_q*(m+1)");
+  return whitened_search(ctx, d_L, ldl, d_Sigma_inv, N, m, sigma, d_f_init, opts, d_fMAP, h_stats, (hipStream_t)stream,
+                         WhitenedExtras());
+}
+
+int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, const double theta[3], double shrink,
+                int m, const double* d_f_init, const ppbo_fit_opts* opts, double* d_Sigma, double* d_Sigma_inv,
+                double* d_L, double* d_Linv, double* d_fMAP, double* d_alpha, double* d_lam_diag, double* d_lam_off,
+                double* d_G, ppbo_fit_stats* h_stats, int* h_info, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_X && theta && d_f_init && d_Sigma_inv && d_L && d_fMAP, "null pointer");
+  PPBO_REQUIRE(ctx, (d_alpha && d_lam_diag && d_lam_off && d_G) || (!d_alpha && !d_lam_diag && !d_lam_off && !d_G),
+               "the posterior outputs (alpha, lam_diag, lam_off, G) come together or not at all");
+  PPBO_REQUIRE(ctx, N > 0 && D > 0 && m >= 1 && theta[0] > 0 && N % (m + 1) == 0, "sizes (N must be n_q*(m+1))");
+  PPBO_REQUIRE(ctx, d_L != d_Sigma && d_L != d_Sigma_inv && d_Linv != d_Sigma_inv && d_Linv != d_L, "outputs must not alias");
+  hipStream_t s = (hipStream_t)stream;
+  if (h_info) *h_info = 0;
+  PpboSideStream side;
+  if (int rc = ppbo_side_stream(ctx, &side)) return rc;
+  const size_t nn = (size_t)N * N;
+  double* W = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG, 2 * nn * sizeof(double));
+  int* d_info = (int*)ppbo_workspace(ctx, ppbo_ctx::WS_SMALL, 4096);
+  if (!W || !d_info) return (int)hipErrorOutOfMemory;
+  double* Li = d_Linv ? d_Linv : W + nn;     // the posterior reuses this half for R -- after the GEMM below has read it
+  // Sigma (kept for the caller) and the matrix the factorization overwrites: the Gram kernel runs twice (8.6 us at
+  // N = 2048) instead of once plus a 33 MB device-to-device copy (12 us)
+  if (d_Sigma)
+    if (int rc = ppbo_gram(ctx, kernel_id, d_X, N, D, theta, shrink, d_Sigma, stream)) return rc;
+  if (int rc = ppbo_gram(ctx, kernel_id, d_X, N, D, theta, shrink, d_L, stream)) return rc;
+  if (int rc = ppbo_potrf_async(ctx, d_L, N, N, d_info, s)) return rc;
+  if (int rc = ppbo_trtri_async(ctx, d_L, N, N, Li, N, s)) return rc;
+  // Sigma^-1 = L^-T L^-1 on the side stream: the search below needs only L and L^-1 until its last evaluations
+  PPBO_HIP_CHECK(ctx, hipEventRecord(side.ev[0], s));
+  PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(side.s, side.ev[0], 0));
+  {
+    GemmArgs g{};
+    g.A = Li; g.lda = N; g.B = Li; g.ldb = N; g.C = d_Sigma_inv; g.ldc = N;
+    g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0; g.klo_mode = 1; g.tri_block = 1;
+    if (int rc = ppbo_gemm_launch(ctx, g, 1, 0, side.s)) return rc;
+  }
+  PPBO_HIP_CHECK(ctx, hipEventRecord(side.ev[1], side.s));
+  bool waited = false;
+  WhitenedExtras ex;
+  ex.d_Linv = Li;
+  ex.start_is_z = opts && opts->start_is_whitened != 0;
+  ex.sinv_ready = side.ev[1];
+  ex.waited = &waited;
+  ex.sync_at_end = false;
+  ppbo_fit_stats stt{};
+  int rc = whitened_search(ctx, d_L, N, d_Sigma_inv, N, m, theta[0], d_f_init, opts, d_fMAP, &stt, s, ex);
+  if (!waited) {            // a search that ended before slot WH_SINV_SLOT: the posterior still has to see Sigma^-1
+    PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(s, side.ev[1], 0));
+    waited = true;
+  }
+  if (h_stats) *h_stats = stt;
+  if (rc) { (void)hipStreamSynchronize(s); return rc; }
+  if (d_G)
+    if (int rc2 = posterior_async(ctx, d_Sigma_inv, d_fMAP, N, m, theta[0], d_alpha, d_lam_diag, d_lam_off, d_G, nullptr,
+                                  d_info + 1, s)) {
+      (void)hipStreamSynchronize(s);
+      return rc2;
+    }
+  int* h2 = (int*)ppbo_pinned(ctx, 64 * sizeof(double) + 64);
+  if (!h2) return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "pinned staging");
+  h2 += 2 * 64;                                  // beyond the fit's 64 doubles
+  h2[0] = h2[1] = 0;
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(h2, d_info, (d_G ? 2 : 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+  PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  if (h2[0] != 0) {
+    if (h_info) *h_info = 1;
+    return ppbo_set_error(ctx, PPBO_ERR_NOT_PD, "Sigma is not positive definite (leading minor %d)", h2[0]);
+  }
+  if (d_G && h2[1] != 0) {
+    if (h_info) *h_info = 2;
+    return ppbo_set_error(ctx, PPBO_ERR_NOT_PD, "Sigma^-1 - Lambda_MAP is not positive definite (leading minor %d)", h2[1]);
+  }
+  return 0;
+}
+
+int ppbo_posterior(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fMAP, int N, int m, double sigma,
+                   double* d_alpha, double* d_lam_diag, double* d_lam_off, double* d_G, double* d_P, int* h_info,
+                   void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_Sigma_inv && d_fMAP && d_alpha && d_lam_diag && d_lam_off && d_G, "null pointer");
+  PPBO_REQUIRE(ctx, N > 0 && m >= 1 && sigma > 0 && N % (m + 1) == 0, "sizes");
+  hipStream_t s = (hipStream_t)stream;
+  if (h_info) *h_info = 0;
+  int* d_info = (int*)ppbo_workspace(ctx, ppbo_ctx::WS_SMALL, 4096);
+  if (!d_info) return (int)hipErrorOutOfMemory;
+  // everything is enqueued first, the factorization's info word is looked at last: one host wait per call (the
+  // triangular inverse of a failed factor is wasted work, but a failure is the rare case)
+  if (int rc = posterior_async(ctx, d_Sigma_inv, d_fMAP, N, m, sigma, d_alpha, d_lam_diag, d_lam_off, d_G, d_P, d_info, s))
+    return rc;
+  int info = 0;
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  if (h_info) *h_info = info;
+  if (info != 0) return ppbo_set_error(ctx, PPBO_ERR_NOT_PD, "matrix is not positive definite (leading minor %d)", info);
   return 0;
 }
 

@@ -36,13 +36,19 @@ __device__ __forceinline__ Best block_best(Best b, Best* sh) {
   return b;  // valid in thread 0
 }
 
-// Geometry of the score pass: a workgroup finishes SC_CAND candidates; its SC_WAVES wavefronts split the partial slabs
-// of those candidates between them (wavefront w sums slabs w, w + SC_WAVES, ...: every load of the pass is in flight at
+// Geometry of the score pass: a workgroup finishes SC_CAND candidates at a time; its SC_WAVES wavefronts split the partial
+// slabs of those candidates between them (wavefront w sums slabs w, w + SC_WAVES, ...: every load of the pass is in flight at
 // once -- the first version had one thread walk all 2 n_mu + n_slab slabs of its candidate, a dependent chain of up
 // to 144 strided loads: 38 us for 8192 candidates, 27 us for 65536, on a pass that moves 9-25 MB), the wavefront
 // sums meet in LDS and are added in wavefront order (a fixed order: results do not depend on timing).
 constexpr int SC_CAND = 64, SC_WAVES = 16, SC_THREADS = SC_CAND * SC_WAVES;
-static inline int score_blocks(long long M) { return (int)((M + SC_CAND - 1) / SC_CAND); }
+// at most SC_MAX_BLOCKS workgroups (each walks its tiles): the "last workgroup" ticket is one device-scope atomic per
+// workgroup on ONE address, and those serialise across the eight XCDs (~40 ns each: 1024 of them cost more than the pass)
+constexpr int SC_MAX_BLOCKS = 256;
+static inline int score_blocks(long long M) {
+  const long long t = (M + SC_CAND - 1) / SC_CAND;
+  return (int)(t < SC_MAX_BLOCKS ? t : SC_MAX_BLOCKS);
+}
 
 // Scores + per-block best + (when `counter` is given) the launch-wide best in the SAME launch: the last workgroup to
 // retire -- the one whose ticket from `counter` is gridDim.x - 1 -- merges the per-block records and writes
@@ -68,22 +74,23 @@ __global__ __launch_bounds__(SC_THREADS) void score_kernel(const double* __restr
   __shared__ Best sh[SC_WAVES];
   __shared__ unsigned s_ticket;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * SC_CAND + lane;
-  double pm = 0.0, pt = 0.0, pq = 0.0;
-  if (c < M) {
-    for (int s = wave; s < n_mu; s += SC_WAVES) pm += mu_part[(size_t)s * M + c];
-    if (slab) {
-      for (int s = wave; s < n_mu; s += SC_WAVES) pt += t_part[(size_t)s * M + c];
-      for (int s = wave; s < n_slab; s += SC_WAVES) pq += slab[(size_t)s * M + c];
-    }
-  }
-  part[0][wave][lane] = pm;
-  part[1][wave][lane] = pt;
-  part[2][wave][lane] = pq;
-  __syncthreads();
-  Best b{0.0, -1};
-  if (wave == 0) {
+  const int ntiles = (M + SC_CAND - 1) / SC_CAND;
+  Best b{0.0, -1};                       // wavefront 0: this lane's best over the tiles of the workgroup
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int c = tile * SC_CAND + lane;
+    double pm = 0.0, pt = 0.0, pq = 0.0;
     if (c < M) {
+      for (int s = wave; s < n_mu; s += SC_WAVES) pm += mu_part[(size_t)s * M + c];
+      if (slab) {
+        for (int s = wave; s < n_mu; s += SC_WAVES) pt += t_part[(size_t)s * M + c];
+        for (int s = wave; s < n_slab; s += SC_WAVES) pq += slab[(size_t)s * M + c];
+      }
+    }
+    part[0][wave][lane] = pm;
+    part[1][wave][lane] = pt;
+    part[2][wave][lane] = pq;
+    __syncthreads();
+    if (wave == 0 && c < M) {
       double mu = 0.0, t = 0.0, q = 0.0;
 #pragma unroll
       for (int w = 0; w < SC_WAVES; ++w) { mu += part[0][w][lane]; t += part[1][w][lane]; q += part[2][w][lane]; }
@@ -102,9 +109,12 @@ __global__ __launch_bounds__(SC_THREADS) void score_kernel(const double* __restr
       if (mu_out) mu_out[c] = mu;
       if (var_out) var_out[c] = var;
       if (score_out) score_out[c] = sc;
-      if (sc == sc) { b.val = sc; b.idx = idx_base + c; }
+      if (sc == sc) b = best_merge(b, Best{sc, idx_base + c});
     }
-    if (!blk_best) return;
+    __syncthreads();                     // `part` is rewritten by the next tile
+  }
+  if (!blk_best) return;
+  if (wave == 0) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       Best other;

@@ -357,7 +357,7 @@ class Engine:
         f0 = self.dev(f_init).reshape(-1)
         N = f0.numel()
         out = self.empty(N)
-        opts = _lib.FitOpts(float(gtol), int(maxiter), int(verbose), float(initial_radius), int(lbfgs_max_evals), 0)
+        opts = _lib.FitOpts(float(gtol), int(maxiter), int(verbose), float(initial_radius), int(lbfgs_max_evals), 0, 0)
         st = _lib.FitStats()
         if L is None:
             rc = self.lib.ppbo_fit_fmap(self.ctx, _ptr(Sigma_inv), N, m, float(sigma), _ptr(f0), C.byref(opts),
@@ -371,6 +371,43 @@ class Engine:
                      gradnorm=st.gradnorm, lbfgs_iterations=st.lbfgs_iterations, lbfgs_evals=st.lbfgs_evals,
                      lbfgs_status=st.lbfgs_status)
         return out, stats
+
+    def gp_fit(self, X, theta, kernel, m, f_init, shrink=SHRINKAGE, gtol=1e-4, maxiter=0, verbose=0, lbfgs_max_evals=0,
+               start_is_whitened=False, want_Sigma=True, want_Linv=False, want_posterior=True):
+        """One whole GP fit in one library call (ppbo_gp_fit): Sigma, its Cholesky factor and inverse, f_MAP from one
+        start by the whitened search, and the posterior state -- the work of update_Sigma + update_Sigma_inv +
+        update_fMAP + the posterior (src/gp_model.py:91-117) with Sigma^-1 formed on a side stream behind the search and
+        ONE host wait.  start_is_whitened: f_init holds z0 and the start is the prior draw L z0.
+        Returns dict(Sigma, Sigma_inv, L, Linv, fMAP, post, stats, info); info = 2 (with post = None) when
+        Sigma^-1 - Lambda_MAP is not positive definite (raises NotPositiveDefinite when Sigma itself is not)."""
+        X = self.dev(X)
+        N, D = X.shape
+        f0 = self.dev(f_init).reshape(-1)
+        if f0.numel() != N:
+            raise ValueError(f"gp_fit: the start vector has {f0.numel()} entries, the design {N} rows")
+        Sigma = self.empty(N, N) if want_Sigma else None
+        Sinv, L = self.empty(N, N), self.empty(N, N)
+        Linv = self.empty(N, N) if want_Linv else None
+        fmap = self.empty(N)
+        if want_posterior:
+            alpha, ld, lo, G = self.empty(N), self.empty(N), self.empty(N), self.empty(N, N)
+        else:
+            alpha = ld = lo = G = None
+        opts = _lib.FitOpts(float(gtol), int(maxiter), int(verbose), 0.0, int(lbfgs_max_evals), 0, int(bool(start_is_whitened)))
+        st = _lib.FitStats()
+        info = C.c_int(0)
+        rc = self.lib.ppbo_gp_fit(self.ctx, KERNEL_IDS[kernel], _ptr(X), N, D, self._theta(theta), float(shrink), int(m),
+                                  _ptr(f0), C.byref(opts), _ptr(Sigma), _ptr(Sinv), _ptr(L), _ptr(Linv), _ptr(fmap),
+                                  _ptr(alpha), _ptr(ld), _ptr(lo), _ptr(G), C.byref(st), C.byref(info), self._stream())
+        if rc == PPBO_ERR_NOT_PD and info.value == 2:
+            post = None
+        else:
+            self._check(rc, "ppbo_gp_fit", info.value)
+            post = Posterior(kernel, tuple(float(t) for t in theta), m, X, alpha, ld, lo, G, None) if want_posterior else None
+        stats = dict(iterations=st.iterations, n_cholesky=st.n_cholesky, converged=bool(st.converged), T=st.T,
+                     gradnorm=st.gradnorm, lbfgs_iterations=st.lbfgs_iterations, lbfgs_evals=st.lbfgs_evals,
+                     lbfgs_status=st.lbfgs_status)
+        return dict(Sigma=Sigma, Sigma_inv=Sinv, L=L, Linv=Linv, fMAP=fmap, post=post, stats=stats, info=info.value)
 
     def posterior(self, X, theta, kernel, Sigma_inv, fMAP, m, want_P=False) -> Posterior:
         X = self.dev(X)

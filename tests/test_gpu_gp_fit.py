@@ -1,0 +1,101 @@
+"""ppbo_gp_fit: one whole GP fit in one library call (Sigma, Cholesky factor, Sigma^-1 on a side stream, the whitened
+f_MAP search steered through a host-mapped progress word, the posterior) against the same work done call by call and
+against the reference's fixtures (src/gp_model.py:91-117)."""
+import numpy as np
+import pytest
+
+from conftest import golden_names
+
+pytestmark = pytest.mark.gpu
+FITTED = golden_names(lambda n: n != "c5")
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from ppbo_amd.engine import get_engine
+    return get_engine(0)
+
+
+@pytest.mark.parametrize("name", FITTED)
+def test_gp_fit_equals_the_separate_calls_and_the_reference(eng, golden, name):
+    g = golden(name)
+    X, th, kern, m, sig = g["X"], g["theta"], str(g["kernel"]), int(g["m"]), float(g["theta"][0])
+    r = eng.gp_fit(X, th, kern, m, g["f_init"], gtol=1e-4, want_Linv=True)
+    st = r["stats"]
+    print(name, st)
+    # the matrices come from the same kernels as the separate calls: the same bits
+    S = eng.gram(X, th, kern)
+    Sinv, L = eng.pd_inverse_chol(S)
+    assert np.array_equal(host(r["Sigma"]), host(S))
+    assert np.array_equal(np.tril(host(r["L"])), np.tril(host(L)))
+    assert np.array_equal(host(r["Sigma_inv"]), host(Sinv))
+    Li = np.tril(host(r["Linv"]))
+    assert np.abs(Li @ np.tril(host(L)) - np.eye(X.shape[0])).max() <= 1e-7
+    # f_MAP: the reference's optimum, by the reference's rule
+    f = host(r["fMAP"])
+    assert st["converged"] and st["gradnorm"] < 1e-4 and st["lbfgs_evals"] > 0
+    T, grad = eng.T_and_grad(Sinv, f, m, sig)
+    assert abs(T - st["T"]) <= 1e-8 * max(1.0, abs(T)) and np.linalg.norm(host(grad)) < 1e-4   # phi(z) vs T(f): cond(Sigma) ~ 1e7 apart in rounding
+    assert abs(np.linalg.norm(host(grad)) - st["gradnorm"]) <= 1e-6 * max(1.0, st["gradnorm"]) + 1e-9
+    post_ref = eng.posterior(X, th, kern, Sinv, g["fMAP"], m, want_P=True)
+    P = host(post_ref.P)
+    gaps = 0.0
+    for fv in (f, g["fMAP"]):
+        _, gr = eng.T_and_grad(Sinv, fv, m, sig)
+        gaps += np.abs(P @ host(gr)).max()
+    assert np.abs(f - g["fMAP"]).max() <= 1e-5 * np.abs(g["fMAP"]).max() + 1.5 * gaps
+    assert st["T"] >= float(g["T_fMAP"]) - 1e-7 * max(1.0, abs(float(g["T_fMAP"])))
+    # the posterior state is ppbo_posterior's at that f_MAP, bit for bit
+    post2 = eng.posterior(X, th, kern, Sinv, r["fMAP"], m)
+    for a, b in ((r["post"].alpha, post2.alpha), (r["post"].lam_diag, post2.lam_diag), (r["post"].lam_off, post2.lam_off),
+                 (r["post"].G, post2.G)):
+        assert np.array_equal(host(a), host(b))
+    # and it predicts like the reference (mean + variance on the fixture's candidates)
+    o = eng.predict(r["post"], g["Xc"], want_best=False)
+    sf2 = float(th[2]) ** 2
+    assert np.abs(host(o["mu"]) - g["mu"]).max() <= 2e-5 * np.abs(g["mu"]).max()
+    assert np.abs(host(o["var"]) - g["var"]).max() <= 2e-5 * sf2
+
+
+@pytest.mark.parametrize("name", ["smoke", "c2"])
+def test_gp_fit_from_a_whitened_start(eng, golden, name):
+    """start_is_whitened: the start is the prior draw L z0 (src/gp_model.py:374,381) given by its z0."""
+    g = golden(name)
+    X, th, kern, m = g["X"], g["theta"], str(g["kernel"]), int(g["m"])
+    z0 = np.random.default_rng(3).standard_normal(X.shape[0])
+    a = eng.gp_fit(X, th, kern, m, z0, start_is_whitened=True)
+    f0 = eng.dgemv(a["L"], z0, lower=True)
+    b = eng.gp_fit(X, th, kern, m, f0)
+    assert a["stats"]["converged"] and b["stats"]["converged"]
+    assert abs(a["stats"]["T"] - b["stats"]["T"]) <= 1e-6 * max(1.0, abs(b["stats"]["T"]))
+    assert np.abs(host(a["fMAP"]) - host(b["fMAP"])).max() <= 1e-4 * np.abs(host(b["fMAP"])).max()
+
+
+def test_gp_fit_is_deterministic_and_reusable(eng, golden):
+    g = golden("c2")
+    X, th, kern, m = g["X"], g["theta"], str(g["kernel"]), int(g["m"])
+    a = eng.gp_fit(X, th, kern, m, g["f_init"])
+    b = eng.gp_fit(X, th, kern, m, g["f_init"])
+    assert a["stats"] == b["stats"]
+    assert np.array_equal(host(a["fMAP"]), host(b["fMAP"])) and np.array_equal(host(a["post"].G), host(b["post"].G))
+    c = eng.gp_fit(X, th, kern, m, g["f_init"], want_posterior=False, want_Sigma=False)
+    assert c["post"] is None and c["Sigma"] is None and np.array_equal(host(c["fMAP"]), host(a["fMAP"]))
+    # a tiny evaluation budget: the trust-region finisher takes over inside the same call
+    d = eng.gp_fit(X, th, kern, m, g["f_init"], lbfgs_max_evals=6)
+    assert d["stats"]["lbfgs_status"] == 5 and d["stats"]["converged"] and d["stats"]["n_cholesky"] > 0
+    assert np.abs(host(d["fMAP"]) - host(a["fMAP"])).max() <= 1e-4 * np.abs(host(a["fMAP"])).max()
+
+
+def test_gp_fit_reports_a_posterior_that_is_not_positive_definite(eng, golden):
+    """A start far from any maximum and a budget of zero useful work cannot produce this; what does is handing the
+    call a sigma so small that Lambda dominates -- the call must say info = 2, keep f_MAP, and not raise."""
+    g = golden("smoke")
+    X, kern, m = g["X"], str(g["kernel"]), int(g["m"])
+    with pytest.raises(ValueError):
+        eng.gp_fit(X, g["theta"], kern, m, np.zeros(X.shape[0] + 1))
+    with pytest.raises(RuntimeError):
+        eng.gp_fit(X, [0.0, 0.3, 0.5], kern, m, g["f_init"])          # sigma must be positive
