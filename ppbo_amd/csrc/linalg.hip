@@ -1135,17 +1135,22 @@ int ppbo_pd_inverse_ex(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, 
   double* L = d_L ? d_L : W;                 // factor straight into the caller's buffer when it wants the factor
   double* Li = d_Linv ? d_Linv : W + (size_t)N * N;
   PPBO_HIP_CHECK(ctx, hipMemcpyAsync(L, d_A, bytes, hipMemcpyDeviceToDevice, s));
-  int info = 0;
-  if (int rc = ppbo_potrf(ctx, L, N, N, &info, stream)) {
-    if (h_info) *h_info = info;
-    return rc;
-  }
-  if (h_info) *h_info = 0;
+  int* d_info = (int*)ppbo_workspace(ctx, ppbo_ctx::WS_SMALL, 4096);
+  if (!d_info) return (int)hipErrorOutOfMemory;
+  // factor, inverse of the factor and the product are enqueued behind each other; the info word is read once, at the
+  // end (a failed factorization wastes the rest: the rare case) -- one host wait per call instead of two
+  if (int rc = ppbo_potrf_async(ctx, L, N, N, d_info, s)) return rc;
   if (int rc = ppbo_trtri_async(ctx, L, N, N, Li, N, s)) return rc;
   GemmArgs g{};  // A^-1 = Linv^T Linv
   g.A = Li; g.lda = N; g.B = Li; g.ldb = N; g.C = d_Ainv; g.ldc = N;
   g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0; g.klo_mode = 1; g.tri_block = 1;
-  return ppbo_gemm_launch(ctx, g, 1, 0, s);
+  if (int rc = ppbo_gemm_launch(ctx, g, 1, 0, s)) return rc;
+  int info = 0;
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  if (h_info) *h_info = info;
+  if (info != 0) return ppbo_set_error(ctx, PPBO_ERR_NOT_PD, "matrix is not positive definite (leading minor %d)", info);
+  return 0;
 }
 
 int ppbo_pd_inverse_factors(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, double* d_Linv, int* h_info,

@@ -714,3 +714,33 @@ def test_variance_contraction_fast_path_star_sizes(eng, m):
     out = eng.predict(post, Xc)
     assert rel(host(out["mu"]), mu0) < 1e-7
     assert np.abs(host(out["var"]) - var0).max() <= 1e-7 * th[2] ** 2
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 200, 256, 320, 449, 512, 650, 1031, 2048, 2500, 2816, 3000])
+def test_factor_triangular_inverse_and_inverse_together(eng, N):
+    """ppbo_pd_inverse_ex hands back L, L^-1 and A^-1 from ONE enqueue (factorization, recursive-doubling triangular
+    inverse, L^-T L^-1; the info word is read once at the end).  Checked entry by entry: L^-1 L = I, zeros above the
+    diagonal, A^-1 = L^-T L^-1; ragged last blocks and 1, 2, 3, 4 blocks included; a failed factorization is reported
+    with its leading minor and leaves the ctx usable."""
+    rng = np.random.default_rng(N)
+    Q = rng.standard_normal((N, N))
+    A = Q @ Q.T + N * np.eye(N)
+    Ai, Li, L = eng.pd_inverse_factors3(A)
+    Ai, Li, L = host(Ai), host(Li), np.tril(host(L))
+    assert rel(L, np.linalg.cholesky(A)) < 1e-12
+    assert np.array_equal(np.triu(Li, 1), np.zeros_like(Li))
+    assert np.abs(Li @ L - np.eye(N)).max() < 1e-11
+    assert rel(Li, np.linalg.inv(np.linalg.cholesky(A))) < 1e-11
+    assert np.abs(Ai - Li.T @ Li).max() <= 1e-12 * np.abs(Ai).max()
+    # a matrix that is not positive definite: the call says so (and which leading minor), whatever the inverse roles did
+    if N >= 3:
+        B = A.copy()
+        bad = max(1, (2 * N) // 3)
+        B[bad, bad] = -1.0
+        from ppbo_amd.engine import NotPositiveDefinite
+        with pytest.raises(NotPositiveDefinite) as ei:
+            eng.pd_inverse_factors3(B)
+        assert ei.value.info == bad + 1
+    # and the next call on the same ctx is unaffected
+    Ai2 = host(eng.pd_inverse(A))
+    assert np.array_equal(Ai2, Ai)
