@@ -203,9 +203,7 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
  * replaces update_Sigma + update_Sigma_inv + update_fMAP (one trial from d_f_init) + create_Lambda + the posterior
  * covariance (src/gp_model.py:91-117) -- i.e. ppbo_gram, ppbo_pd_inverse_ex, ppbo_fit_fmap_whitened and
  * ppbo_posterior behind one entry, with what that allows:
- *   - Sigma^-1 = L^-T L^-1 is formed on the ctx's side stream while the whitened search (which needs only L and, for
- *     z0, L^-1) already runs on `stream`; the search asks for |grad_f T| (which needs Sigma^-1) from its fifth
- *     evaluation on, behind an event;
+ *   - the start is whitened with the factor's inverse that is at hand anyway (z0 = L^-1 f_init: one triangular product);
  *   - no host wait between the phases: the two factorizations' info words and the search's state are read once, at
  *     the end (the search itself is steered through a host-mapped progress word, not through stream synchronisation).
  * Outputs (device, caller-owned): d_Sigma [N,N] (NULL to skip), d_Sigma_inv [N,N], d_L [N,N] (Cholesky factor of

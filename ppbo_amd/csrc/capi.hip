@@ -64,32 +64,6 @@ unsigned* ppbo_ticket_counter(ppbo_ctx* ctx) {
   return ctx->ticket;
 }
 
-int ppbo_side_stream(ppbo_ctx* ctx, PpboSideStream* out) {
-  if (!ctx->side_stream) {
-    // Every other CU: what runs here (a GEMM that would otherwise occupy every CU with long-lived workgroups) must
-    // leave room for the latency-bound launches of the caller's stream it is meant to overlap with -- measured without
-    // the mask: a 512-workgroup helper kernel of the main stream took 132 us instead of 10 behind the Sigma^-1 GEMM.
-    hipStream_t st = nullptr;
-    uint32_t mask[8];
-    for (int i = 0; i < 8; ++i) mask[i] = 0x55555555u;
-    if (env_int("PPBO_SIDE_CU_MASK", 1) == 0 || hipExtStreamCreateWithCUMask(&st, 8, mask) != hipSuccess) {
-      (void)hipGetLastError();
-      PPBO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    }
-    for (int i = 0; i < 2; ++i) {
-      if (hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming) != hipSuccess) {
-        (void)hipStreamDestroy(st);
-        return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "side-stream events");
-      }
-    }
-    ctx->side_stream = st;
-  }
-  out->s = ctx->side_stream;
-  out->ev[0] = ctx->side_ev[0];
-  out->ev[1] = ctx->side_ev[1];
-  return 0;
-}
-
 int ppbo_host_record(ppbo_ctx* ctx, PpboHostRecord* out) {
   if (!ctx->hostrec) {
     void* h = nullptr;
@@ -176,9 +150,6 @@ int ppbo_ctx_destroy(ppbo_ctx* ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->ticket) (void)hipFree(ctx->ticket);
   if (ctx->hostrec) (void)hipHostFree(ctx->hostrec);
-  for (int i = 0; i < 2; ++i)
-    if (ctx->side_ev[i]) (void)hipEventDestroy(ctx->side_ev[i]);
-  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   for (int i = 0; i < ppbo_ctx::PF_COUNT; ++i)
     for (auto& pr : ctx->pf_events[i]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   }

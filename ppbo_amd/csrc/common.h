@@ -40,19 +40,10 @@ struct ppbo_ctx {
   unsigned* ticket = nullptr;        // device word, zero between launches: the "last workgroup" ticket of score_kernel
   // host-mapped (pinned, device-visible) result record: [0] value, [1] index as a double, [2] the epoch flag the
   // publishing kernel raises last; the host polls it (ppbo_host_record_wait)
-  hipStream_t side_stream = nullptr; // created on first use (ppbo_side_stream): work that overlaps the caller's stream
-  hipEvent_t side_ev[2] = {nullptr, nullptr};
   double* hostrec = nullptr;         // host address
   double* hostrec_dev = nullptr;     // the same memory as the device sees it
   unsigned long long hostrec_epoch = 0;
 };
-
-struct PpboSideStream {
-  hipStream_t s;
-  hipEvent_t ev[2];                  // timing disabled: ordering only
-};
-// the ctx's side stream and two events (created on first use, destroyed with the ctx)
-int ppbo_side_stream(ppbo_ctx* ctx, PpboSideStream* out);
 
 struct PpboHostRecord {
   double* d_rec;                     // device view of the record (2 doubles)

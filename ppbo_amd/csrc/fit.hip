@@ -324,7 +324,7 @@ struct WhState {
   int status;      // 0 running, 1 converged (|grad_f| < gtol), 2 stagnated at the rounding floor, 3 line search
                    // failed along steepest descent, 4 non-finite objective at the start, 5 evaluation budget spent
   int evals, iters, hist, head, first, ls, stall, need_gf, max_evals;
-  int gf_avail;    // 0 while Sigma^-1 is still being formed on the side stream (ppbo_gp_fit): |grad_f| cannot be asked for yet
+  int gf_avail;    // 0: Sigma^-1 f is not available to the judgement (|grad_f| cannot be asked for); always 1 today
   int pad_;
   double phi, dphi, alpha, gz2, gf2, gate, gtol2, gzbest;
   double B[LB_NB * LB_NB];
@@ -701,7 +701,6 @@ __global__ __launch_bounds__(LB_T) void lbfgs_step_kernel(WhState* __restrict__ 
   lbfgs_step<LB_T>(st, N, m, n_q, z, zt, d, u, v, beta, tq, basis, dbg, prog);
 }
 
-__global__ void set_int_flag_kernel(int* p, int v) { *p = v; }
 
 // beta(f) and u = L^T beta in ONE launch: every workgroup rebuilds beta for itself in LDS (N exponentials -- cheaper
 // than a dependent launch), then each wavefront owns one row of the row-major copy U of L^T (zero left of the
@@ -1154,13 +1153,8 @@ constexpr int WH_AHEAD = 3;
 struct WhitenedExtras {
   const double* d_Linv = nullptr;    // when given: z0 = L^-1 f_init by one triangular product (else L^T (Sigma^-1 f_init))
   bool start_is_z = false;           // d_f_init IS z0
-  hipEvent_t sinv_ready = nullptr;   // when given: Sigma^-1 is still being formed on another stream; the search starts
-                                     // without it (|grad_f| is not asked for: gf_avail = 0) and waits for the event in
-                                     // front of slot WH_SINV_SLOT, far enough in for the GEMM (on half of the CUs) to have finished
-  bool* waited = nullptr;            // set once the stream has been made to wait for sinv_ready
   bool sync_at_end = true;           // false: d_fMAP is only enqueued (the caller synchronises later)
 };
-constexpr int WH_SINV_SLOT = 8;
 
 int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m, double sigma,
                     const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP, ppbo_fit_stats* h_stats,
@@ -1189,7 +1183,7 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
   *h_word = 0;                          // nothing of this ctx is in flight that could write it (one search per ctx at a time)
   PPBO_HIP_CHECK(ctx, hipMemsetAsync(base, 0, (st_doubles + (size_t)LB_NB * N) * sizeof(double), s));
   row_sqnorm_kernel<<<(N + 3) / 4, 256, 0, s>>>(d_L, N, ldl, rowsq);
-  lbfgs_init_kernel<<<1, LB_T, 0, s>>>(st, rowsq, N, gtol, max_evals, ex.sinv_ready ? 0 : 1);
+  lbfgs_init_kernel<<<1, LB_T, 0, s>>>(st, rowsq, N, gtol, max_evals, 1);
   PPBO_LAUNCH_CHECK(ctx);
   if (ex.start_is_z) {
     PPBO_HIP_CHECK(ctx, hipMemcpyAsync(zt, d_f_init, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1225,18 +1219,16 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
     if (fused) {
       beta_lt_kernel<<<(N + 3) / 4, 256, blds, s>>>(&st->status, ft, N, mblk, n_q, sigma, U, beta, tq, u);
     } else {
-      laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(ft, N, mblk, n_q, sigma, tq, beta, nullptr, nullptr);
-      if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, beta, u, 1, 1, s, run)) return rc;               // u = L^T beta
+      // u = L^T beta(f): beta rebuilt inside the product's first pass where the star size allows (m = 31: yes)
+      const int rcb = ppbo_gemvT_beta_async(ctx, d_L, N, ldl, ft, mblk, sigma, u, beta, tq, s, run);
+      if (rcb > 1) return rcb;
+      if (rcb == 1) {
+        laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(ft, N, mblk, n_q, sigma, tq, beta, nullptr, nullptr);
+        if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, beta, u, 1, 1, s, run)) return rc;             // u = L^T beta
+      }
     }
     if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, ft, v, 0, 0, s, run_gf)) return rc;          // v = Sigma^-1 f
     lbfgs_step_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, v, beta, tq, basis, dbg, prog);
-    return 0;
-  };
-  auto wait_sinv = [&]() -> int {
-    if (!ex.sinv_ready || (ex.waited && *ex.waited)) return 0;
-    PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(s, ex.sinv_ready, 0));
-    set_int_flag_kernel<<<1, 1, 0, s>>>(&st->gf_avail, 1);
-    if (ex.waited) *ex.waited = true;
     return 0;
   };
   int enq = 0, status = 0, evals = 0;
@@ -1249,8 +1241,6 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
     evals = (int)(w & 0xffffffffu);
     if (status != 0) break;
     if (enq - evals < WH_AHEAD && enq < max_evals + WH_AHEAD) {
-      if (enq == WH_SINV_SLOT)
-        if (int rc = wait_sinv()) return rc;
       if (int rc = enqueue_slot()) return rc;
       ++enq;
       continue;
@@ -1311,7 +1301,6 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
     return 0;
   }
   // finisher: the exact trust-region Newton from there
-  if (int rc = wait_sinv()) return rc;
   ppbo_fit_stats tr{};
   ppbo_fit_opts fin{};
   if (opts) fin = *opts;
@@ -1380,8 +1369,6 @@ int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, c
   PPBO_REQUIRE(ctx, d_L != d_Sigma && d_L != d_Sigma_inv && d_Linv != d_Sigma_inv && d_Linv != d_L, "outputs must not alias");
   hipStream_t s = (hipStream_t)stream;
   if (h_info) *h_info = 0;
-  PpboSideStream side;
-  if (int rc = ppbo_side_stream(ctx, &side)) return rc;
   const size_t nn = (size_t)N * N;
   double* W = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LINALG, 2 * nn * sizeof(double));
   int* d_info = (int*)ppbo_workspace(ctx, ppbo_ctx::WS_SMALL, 4096);
@@ -1394,29 +1381,18 @@ int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, c
   if (int rc = ppbo_gram(ctx, kernel_id, d_X, N, D, theta, shrink, d_L, stream)) return rc;
   if (int rc = ppbo_potrf_async(ctx, d_L, N, N, d_info, s)) return rc;
   if (int rc = ppbo_trtri_async(ctx, d_L, N, N, Li, N, s)) return rc;
-  // Sigma^-1 = L^-T L^-1 on the side stream: the search below needs only L and L^-1 until its last evaluations
-  PPBO_HIP_CHECK(ctx, hipEventRecord(side.ev[0], s));
-  PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(side.s, side.ev[0], 0));
-  {
-    GemmArgs g{};
-    g.A = Li; g.lda = N; g.B = Li; g.ldb = N; g.C = d_Sigma_inv; g.ldc = N;
-    g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0; g.klo_mode = 1; g.tri_block = 1;
-    if (int rc = ppbo_gemm_launch(ctx, g, 1, 0, side.s)) return rc;
-  }
-  PPBO_HIP_CHECK(ctx, hipEventRecord(side.ev[1], side.s));
-  bool waited = false;
+  // Sigma^-1 = L^-T L^-1: the lower triangle on the matrix cores, the upper one mirrored (bitwise symmetric).
+  // (Round 4 also ran this product on a second stream behind the search, which needs only L and L^-1 until its last
+  // evaluations: the GEMM's 1024 short-lived workgroups starve the search's small launches -- a 10 us helper kernel
+  // took 132 us beside it, with a CU mask or a lower stream priority just the same -- so nothing was gained and the
+  // event plumbing went out again: profiles/r04_fit_side_stream.txt.)
+  if (int rc = ppbo_syrk_inverse_async(ctx, Li, N, d_Sigma_inv, s)) return rc;
   WhitenedExtras ex;
   ex.d_Linv = Li;
   ex.start_is_z = opts && opts->start_is_whitened != 0;
-  ex.sinv_ready = side.ev[1];
-  ex.waited = &waited;
   ex.sync_at_end = false;
   ppbo_fit_stats stt{};
   int rc = whitened_search(ctx, d_L, N, d_Sigma_inv, N, m, theta[0], d_f_init, opts, d_fMAP, &stt, s, ex);
-  if (!waited) {            // a search that ended before slot WH_SINV_SLOT: the posterior still has to see Sigma^-1
-    PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(s, side.ev[1], 0));
-    waited = true;
-  }
   if (h_stats) *h_stats = stt;
   if (rc) { (void)hipStreamSynchronize(s); return rc; }
   if (d_G)

@@ -34,6 +34,8 @@ int ppbo_potrf_fail_bound_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl
 // report b in *split_out; the result is then applied with ppbo_apply_linv_async
 int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d_Linv, int ldi, hipStream_t s,
                      int skip_top = 0, int* split_out = nullptr);
+// d_Ainv (N x N, row pitch N) = Linv^T Linv: lower triangle on the matrix cores, upper triangle mirrored
+int ppbo_syrk_inverse_async(ppbo_ctx* ctx, const double* d_Linv, int N, double* d_Ainv, hipStream_t s);
 int ppbo_apply_linv_async(ppbo_ctx* ctx, const double* d_Linv, int ldi, const double* d_L, int ldl, int N, int split,
                           const double* d_x, double* d_y, int trans, double* d_tmp, hipStream_t s);
 // Device-side gate of a launch: the kernel returns at once when *skip_if_nonzero != 0 or *skip_if_zero == 0
@@ -52,5 +54,9 @@ struct PpboGate {
 // y = T x (trans=0) or y = T^T x (trans=1) for a lower-triangular (lower=1) or full N x N matrix
 int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const double* d_x, double* d_y, int trans,
                     int lower, hipStream_t s, PpboGate gate = PpboGate());
+// u = L^T beta(f) in two launches with beta[N] and tq[N / mblk] as by-products (one launch less than laplace_kernel +
+// ppbo_gemv_async); returns 1 without enqueueing anything when mblk is not a multiple of 16 or exceeds 64
+int ppbo_gemvT_beta_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, const double* d_f, int mblk, double sigma,
+                          double* d_u, double* d_beta, double* d_tq, hipStream_t s, PpboGate gate = PpboGate());
 // out[0] = sum_i x_i y_i  (deterministic single-block reduction)
 int ppbo_dot_async(ppbo_ctx* ctx, const double* d_x, const double* d_y, int N, double* d_out, hipStream_t s);

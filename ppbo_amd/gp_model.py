@@ -503,40 +503,82 @@ class GPModel:
         self._post_mean = Posterior(self.kernel.__name__, tuple(float(t) for t in self.theta), self.m, self._dX, alpha,
                                     None, None, None)
 
+    def _fit_fused(self):
+        """The default update (one prior-draw start, whitened search) as ONE library call: ppbo_gp_fit builds Sigma,
+        its factor and inverse, runs the search from the prior draw L z0 -- z0 from the global NumPy stream, exactly the
+        numbers _draw_prior would have consumed -- and the posterior state, with one host wait instead of one per
+        phase (update_Sigma + update_Sigma_inv + update_fMAP + the posterior of src/gp_model.py:91-117).
+        Returns False (nothing done) when the configuration needs the call-by-call path."""
+        if (self.incremental or self.fMAP_method != "whitened" or self.last_iteration or self.fMAP_finding_trials != 1
+                or not self.fMAP_random_initial_vector or self.fMAP_restart_on_stall):
+            return False
+        if self.verbose:
+            print("MAP-estimation begins...")
+        start = time.time()
+        z0 = np.random.standard_normal(self.N)
+        r = self.eng.gp_fit(self._dX, self.theta, self.kernel.__name__, self.m, z0, shrink=self.COVARIANCE_SHRINKAGE,
+                            gtol=self.fMAP_gtol, start_is_whitened=True, want_Sigma=True, want_posterior=True)
+        th = tuple(float(t) for t in self.theta)
+        self._dSigma, self._dSigma_inv, self._dL, self._dLinv = r["Sigma"], r["Sigma_inv"], r["L"], None
+        self._sinv_state = (self.X.copy(), th, 0)
+        self._dL_stale = False
+        self.n_full_inversions += 1
+        self._invalidate("Sigma", "Sigma_inv", "Pinv")
+        st = r["stats"]
+        self.fit_stats = st
+        self.fit_log.append(dict(N=self.N, method="whitened (ppbo_gp_fit)", iterations=st["iterations"],
+                                 n_cholesky=st["n_cholesky"], lbfgs_evals=st["lbfgs_evals"],
+                                 lbfgs_status=st["lbfgs_status"], converged=st["converged"], warm=False,
+                                 seconds=time.time() - start))
+        self.fMAP = r["fMAP"].cpu().numpy()
+        if self.verbose:
+            print("... this took " + str(time.time() - start) + " seconds.")
+            print("Current theta is: " + str(self.theta) + " (Acq. = " + str(self.xi_acquisition_function) + ")")
+            print("Updating Lambda_MAP and posterior covariance...")
+        if r["post"] is not None:
+            self._post = self._post_mean = r["post"]
+            self._invalidate("Lambda_MAP", "P", "Pinv")
+        else:
+            print("---!!!--- Posterior covariance matrix is not PSD ---!!!---")   # gp_model.py:119, keep the old one
+            self._refresh_mean_state(r["fMAP"])
+        return True
+
     # ------------------------------------------------------------------ orchestration (gp_model.py:87-132)
     def update_model(self, optimize_theta=False):
         if self.theta is None:
             self.set_theta()
-        self.update_Sigma(self.theta)
-        self.update_Sigma_inv(self.theta)
         init_skip = self.initialization_running and self.skip_computations_during_initialization
-        if init_skip:
-            self.FP.alpha_grid_distribution = "equispaced"
-            self.update_fMAP(random_initial_vector=False, fmap_finding_trials=1, approx_optimization=True)
-        elif self.last_iteration:
-            self.update_fMAP(random_initial_vector=True, fmap_finding_trials=10)
-        else:
-            self.update_fMAP()
-        if optimize_theta:
-            self.optimize_theta()
-            self.update_fMAP()
+        fused = (not init_skip) and (not optimize_theta) and self._fit_fused()
+        if not fused:
             self.update_Sigma(self.theta)
             self.update_Sigma_inv(self.theta)
-        if self.verbose:
-            print("Current theta is: " + str(self.theta) + " (Acq. = " + str(self.xi_acquisition_function) + ")")
-        if not init_skip:
+            if init_skip:
+                self.FP.alpha_grid_distribution = "equispaced"
+                self.update_fMAP(random_initial_vector=False, fmap_finding_trials=1, approx_optimization=True)
+            elif self.last_iteration:
+                self.update_fMAP(random_initial_vector=True, fmap_finding_trials=10)
+            else:
+                self.update_fMAP()
+            if optimize_theta:
+                self.optimize_theta()
+                self.update_fMAP()
+                self.update_Sigma(self.theta)
+                self.update_Sigma_inv(self.theta)
             if self.verbose:
-                print("Updating Lambda_MAP and posterior covariance...")
-            start = time.time()
-            try:
-                self._post = self.eng.posterior(self._dX, self.theta, self.kernel.__name__, self._dSigma_inv,
-                                                self.eng.dev(self.fMAP), self.m, want_P=False)
-                self._post_mean = self._post
-                self._invalidate("Lambda_MAP", "P", "Pinv")
-            except NotPositiveDefinite:
-                print("---!!!--- Posterior covariance matrix is not PSD ---!!!---")   # gp_model.py:119, keep the old one
-            if self.verbose:
-                print("... this took " + str(time.time() - start) + " seconds.")
+                print("Current theta is: " + str(self.theta) + " (Acq. = " + str(self.xi_acquisition_function) + ")")
+            if not init_skip:
+                if self.verbose:
+                    print("Updating Lambda_MAP and posterior covariance...")
+                start = time.time()
+                try:
+                    self._post = self.eng.posterior(self._dX, self.theta, self.kernel.__name__, self._dSigma_inv,
+                                                    self.eng.dev(self.fMAP), self.m, want_P=False)
+                    self._post_mean = self._post
+                    self._invalidate("Lambda_MAP", "P", "Pinv")
+                except NotPositiveDefinite:
+                    print("---!!!--- Posterior covariance matrix is not PSD ---!!!---")   # gp_model.py:119, keep the old one
+                if self.verbose:
+                    print("... this took " + str(time.time() - start) + " seconds.")
         if self.verbose:
             print("Computing mu_star and x_star ...")
         start = time.time()

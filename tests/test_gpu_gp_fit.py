@@ -54,11 +54,13 @@ def test_gp_fit_equals_the_separate_calls_and_the_reference(eng, golden, name):
     for a, b in ((r["post"].alpha, post2.alpha), (r["post"].lam_diag, post2.lam_diag), (r["post"].lam_off, post2.lam_off),
                  (r["post"].G, post2.G)):
         assert np.array_equal(host(a), host(b))
-    # and it predicts like the reference (mean + variance on the fixture's candidates)
+    # and it predicts like the reference on the fixture's candidates, up to what two f_MAPs that both stop at
+    # |grad| < 1e-4 may differ by (the Newton gaps above; the 1e-6 parity of mean / variance at a FIXED f_MAP is
+    # test_gpu_parity.py's business)
     o = eng.predict(r["post"], g["Xc"], want_best=False)
     sf2 = float(th[2]) ** 2
-    assert np.abs(host(o["mu"]) - g["mu"]).max() <= 2e-5 * np.abs(g["mu"]).max()
-    assert np.abs(host(o["var"]) - g["var"]).max() <= 2e-5 * sf2
+    assert np.abs(host(o["mu"]) - g["mu"]).max() <= 2e-4 * np.abs(g["mu"]).max()
+    assert np.abs(host(o["var"]) - g["var"]).max() <= 2e-4 * sf2
 
 
 @pytest.mark.parametrize("name", ["smoke", "c2"])

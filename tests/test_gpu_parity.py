@@ -541,26 +541,44 @@ def test_error_codes_and_messages(eng, golden):
         eng.profile_read("nope")
 
 
-def test_dropin_posterior_not_psd_prints_and_continues(golden, capsys):
+@pytest.mark.parametrize("method", ["whitened", "trust-region"])
+def test_dropin_posterior_not_psd_prints_and_continues(golden, capsys, method):
+    """src/gp_model.py:118-120: a posterior precision that is not positive definite prints the reference's line and
+    keeps the previous posterior covariance -- on the one-call update (ppbo_gp_fit reports info = 2 and no posterior)
+    and on the call-by-call one (ppbo_posterior raises NotPositiveDefinite)."""
     from test_gpu_dropin import _model
     g = golden("smoke")
     gp, st = _model(g)
+    gp.fMAP_method = method
     gp.turn_initialization_off()
     np.random.seed(2)
     gp.update_model()
+    assert gp.fit_log[-1]["method"].startswith(method)
     old_post = gp._post
     assert old_post is not None
     # force an indefinite posterior precision on the next update
-    real_fit = gp.eng.fit_fmap
     f_bad = np.where(np.arange(gp.N) % (gp.m + 1) != 0, 1.414 * float(gp.theta[0]), 0.0)
+    from ppbo_amd.engine import NotPositiveDefinite
+    with pytest.raises(NotPositiveDefinite):       # the C path itself says so for this f
+        gp.eng.posterior(gp._dX, gp.theta, gp.kernel.__name__, gp._dSigma_inv, f_bad, gp.m)
+    real_fit, real_gp_fit = gp.eng.fit_fmap, gp.eng.gp_fit
     gp.eng.fit_fmap = lambda *a, **k: (gp.eng.dev(f_bad),
                                        dict(iterations=0, n_cholesky=0, converged=False, T=-1.0, gradnorm=1.0))
+
+    def fake_gp_fit(*a, **k):                      # what ppbo_gp_fit hands back when Sigma^-1 - Lambda is not PD
+        r = real_gp_fit(*a, **k)
+        r.update(fMAP=gp.eng.dev(f_bad), post=None, info=2)
+        return r
+
+    gp.eng.gp_fit = fake_gp_fit
     try:
         gp.update_model()
     finally:
-        gp.eng.fit_fmap = real_fit
+        gp.eng.fit_fmap, gp.eng.gp_fit = real_fit, real_gp_fit
     assert "Posterior covariance matrix is not PSD" in capsys.readouterr().out
     assert gp._post is old_post
+    assert np.array_equal(gp.fMAP, f_bad)
+    assert gp._post_mean is not old_post and gp._post_mean.G is None      # the mean follows the new f_MAP
 
 
 @pytest.mark.skipif("c4" not in ALL, reason="c4 fixture missing")
