@@ -302,6 +302,16 @@ int ppbo_shift_points(ppbo_ctx* ctx, const double* d_in, int64_t M, int D, const
 int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, int B, int G,
                   double shrink, const double* d_z, int S, double mustar, double jitter,
                   double* d_ei, double* d_varmax, void* stream);
+/* The same with the grid points formed ON THE DEVICE: line b is {alpha[g] * d_xi[b,:] + d_x[b,:]}, g < G -- what
+ * FeedbackProcessing.xi_grid(xi, x, 'equispaced', m = 70, is_scaled = True) (src/feedback_processing.py:57-107) returns
+ * for the abscissae alpha the caller has drawn (the reference: 70 noisy-equispaced values in [0, 1] per EI call,
+ * src/acquisition.py:72-75).  d_alpha[G] when alpha_per_line == 0 (one abscissa vector shared by all lines: common
+ * random numbers), d_alpha[B,G] otherwise.  Nothing of size B x G x D crosses the host boundary: (xi, x, alpha) are
+ * B x (2 D + G) numbers (EI-EXT at D = 20: 1000 lines, 110 KB instead of an 11 MB grid built by 1000 Python calls). */
+int ppbo_line_acq_xi(ppbo_ctx* ctx, const ppbo_model* model, const double* d_xi, const double* d_x,
+                     const double* d_alpha, int alpha_per_line, int B, int G, double shrink, const double* d_z, int S,
+                     double mustar, double jitter, double* d_ei, double* d_varmax, void* stream);
+
 
 /* standard normal draws for the Monte-Carlo acquisitions, generated on the device: d_out[n] = a pure function of
  * (seed, index) (Philox-4x32-10 + Box-Muller), i.e. reproducible and independent of the launch geometry.  Replaces

@@ -76,6 +76,7 @@ SIGNATURES = {
     "ppbo_mean_ascent": [_vp, C.POINTER(Model), _vp, _i, _i, _d, _vp, _vp, _vp, _vp],
     "ppbo_shift_points": [_vp, _vp, _i64, _i, C.POINTER(_d), _vp, _vp],
     "ppbo_line_acq": [_vp, C.POINTER(Model), _vp, _i, _i, _d, _vp, _i, _d, _d, _vp, _vp, _vp],
+    "ppbo_line_acq_xi": [_vp, C.POINTER(Model), _vp, _vp, _vp, _i, _i, _i, _d, _vp, _i, _d, _d, _vp, _vp, _vp],
     "ppbo_randn": [_vp, C.c_uint64, _vp, _i64, _vp],
     "ppbo_rff_project": [_vp, _vp, _i, _i, _vp, _i, _vp, _d, _vp, _vp],
     "ppbo_rff_score": [_vp, _vp, _i64, _i, _vp, _i, _vp, _d, _vp, _vp, C.POINTER(_d), C.POINTER(_i64), _vp],

@@ -29,31 +29,41 @@ ITERS_PER_ROUND = 5
 SEARCH_DRAW_FACTOR = 8
 
 
+def _noisy_alpha_rows(B):
+    """B independent draws of the reference's 70 noisy-equispaced abscissae on [0, 1] (feedback_processing.py:57-74
+    with is_scaled: linspace(0.005, 0.995, 70) + N(0, 0.01), clipped, sorted, redrawn while two coincide) in ONE NumPy
+    call: B x 70 normals leave the global stream in the order B sequential xi_grid calls would have taken them (a
+    redraw -- two values clipped onto the same boundary: rare -- takes its numbers after the block instead of inside it)."""
+    base = np.linspace(0.005, 0.995, LINE_POINTS)
+    a = np.sort(np.clip(base[None, :] + np.random.normal(0.0, 0.01, (B, LINE_POINTS)), 0.0, 1.0), axis=1)
+    bad = np.where((np.diff(a, axis=1) == 0.0).any(axis=1))[0]
+    while bad.size:
+        a[bad] = np.sort(np.clip(base[None, :] + np.random.normal(0.0, 0.01, (bad.size, LINE_POINTS)), 0.0, 1.0), axis=1)
+        bad = bad[(np.diff(a[bad], axis=1) == 0.0).any(axis=1)]
+    return a
+
+
 def _line_scores(xis, xs, GP_model, mc_samples, z=None, alphas=None):
-    """EI and varmax of B lines in one device call.  Grid noise (and z unless given) come from the global NumPy
-    stream; a caller comparing lines passes ONE z -- and ONE set of grid abscissae `alphas` (the 70 noisy-equispaced
-    alpha of FP.xi_grid, drawn once) -- so that every line sees the same draws (common random numbers)."""
-    FP = GP_model.FP
+    """EI and varmax of B lines in one device call (ppbo_line_acq_xi: the 70 grid points of every line are formed on
+    the device from (xi, x, alpha); the host hands over B x (2 D + 70) numbers, not a B x 70 x D grid built by B
+    Python calls -- 52 ms of host time for the 1000 lines of EI-EXT at D = 20).  Grid noise (and z unless given) come
+    from the global NumPy stream; a caller comparing lines passes ONE z -- and ONE set of grid abscissae `alphas` (the
+    70 noisy-equispaced alpha of FP.xi_grid, drawn once) -- so that every line sees the same draws (common random
+    numbers)."""
+    xis, xs = np.atleast_2d(np.asarray(xis, dtype=float)), np.atleast_2d(np.asarray(xs, dtype=float))
     if alphas is None:
-        grids = np.stack([FP.xi_grid(xi=xi, x=x, alpha_grid_distribution="equispaced", alpha_star=None, m=LINE_POINTS,
-                                     is_scaled=True) for xi, x in zip(xis, xs)])
-    else:       # what xi_grid(is_scaled=True) returns for each line, for one shared alpha vector
-        grids = alphas[None, :, None] * np.asarray(xis, dtype=float)[:, None, :] + np.asarray(xs, dtype=float)[:, None, :]
+        alphas = _noisy_alpha_rows(len(xis))
     if z is None:
         z = np.random.standard_normal((mc_samples, LINE_POINTS))
     sf2 = float(GP_model.theta[2]) ** 2
-    ei, vm = GP_model.eng.line_acq(GP_model._post, grids, z, GP_model.mustar, GP_model.COVARIANCE_SHRINKAGE,
-                                   jitter=1e-10 * sf2)
+    ei, vm = GP_model.eng.line_acq_xi(GP_model._post, xis, xs, alphas, z, GP_model.mustar,
+                                      GP_model.COVARIANCE_SHRINKAGE, jitter=1e-10 * sf2)
     return ei.cpu().numpy(), vm.cpu().numpy()
 
 
 def _noisy_alphas():
     """One draw of the reference's 70 noisy-equispaced abscissae on [0, 1] (feedback_processing.py:57-74, is_scaled)."""
-    while True:
-        a = np.linspace(0.005, 0.995, LINE_POINTS) + np.random.normal(0.0, 0.01, LINE_POINTS)
-        a = np.unique(np.clip(a, 0.0, 1.0))
-        if a.size == LINE_POINTS:
-            return a
+    return _noisy_alpha_rows(1)[0]
 
 
 def EI(xi, x, GP_model, mc_samples):
@@ -116,21 +126,32 @@ def _batched_search(k, lines_of, GP_model, PPBO_settings, which):
 
 def _search_joint(xi_dims, GP_model, PPBO_settings, which, fixed_x=None):
     """maximize_EI / maximize_EI_fixed_x / maximize_varmax (src/acquisition.py:91-131, 189-206): xi free on xi_dims,
-    x free on the complement (or pinned to fixed_x there)."""
+    x free on the complement.  With fixed_x (maximize_EI_fixed_x) only xi's coordinates are searched, and the
+    objective is the REFERENCE's: EI(xi_, xstar) with xi_ = xstar overwritten on xi_dims and the FULL xstar as x
+    (src/acquisition.py:109-113) -- a line through xstar whose direction keeps xstar's own components off xi_dims --
+    although what is returned is (xi zero off xi_dims, x = xstar off xi_dims) as in :124-131."""
     D = GP_model.D
     xi_dims = list(xi_dims)
     x_dims = [i for i in range(D) if i not in xi_dims]
     free = xi_dims + ([] if fixed_x is not None else x_dims)
 
-    def lines_of(U):
+    def result_of(U):
         xis, xs = np.zeros((len(U), D)), np.zeros((len(U), D))
         xis[:, xi_dims] = U[:, :len(xi_dims)]
         xs[:, x_dims] = U[:, len(xi_dims):] if fixed_x is None else np.asarray(fixed_x)[x_dims]
         return xis, xs
 
-    u, log = _batched_search(len(free), lines_of, GP_model, PPBO_settings, which)
+    def scored_lines(U):
+        if fixed_x is None:
+            return result_of(U)
+        xis = np.tile(np.asarray(fixed_x, dtype=float), (len(U), 1))
+        xis[:, xi_dims] = U[:, :len(xi_dims)]
+        return xis, np.tile(np.asarray(fixed_x, dtype=float), (len(U), 1))
+
+    u, log = _batched_search(len(free), scored_lines, GP_model, PPBO_settings, which)
     GP_model.acq_search_log = log
-    xis, xs = lines_of(u[None, :])
+    GP_model.acq_search_scored = tuple(a[0] for a in scored_lines(u[None, :]))     # the line the winning value belongs to
+    xis, xs = result_of(u[None, :])
     return perturbate_zerocoordinates(xis[0], xi_dims), perturbate_zerocoordinates(xs[0], x_dims)
 
 
@@ -176,21 +197,21 @@ def maximize_varmax(xi_dims, GP_model, PPBO_settings):
 
 
 def maximize_varmax_given_xi(xi, GP_model, PPBO_settings):
-    """x maximising varmax for a given direction (src/acquisition.py:208-218); x is zero on xi's support."""
+    """x maximising varmax for a given direction (src/acquisition.py:208-218).  As in the reference, ALL D coordinates
+    of x are searched (the objective is varmax(xi, x) over the whole box: on xi's support x shifts the line along
+    itself) and the coordinates on xi's support are zeroed in the result afterwards (:216-217)."""
     D = GP_model.D
     xi = np.asarray(xi, dtype=float)
-    free = list(np.where(xi == 0)[0])
-    if not free:
-        return np.zeros(D)
 
     def lines_of(U):
-        xs = np.zeros((len(U), D))
-        xs[:, free] = U
-        return np.tile(xi, (len(U), 1)), xs
+        return np.tile(xi, (len(U), 1)), np.asarray(U, dtype=float)
 
-    u, log = _batched_search(len(free), lines_of, GP_model, PPBO_settings, "vm")
+    u, log = _batched_search(D, lines_of, GP_model, PPBO_settings, "vm")
     GP_model.acq_search_log = log
-    return lines_of(u[None, :])[1][0]
+    GP_model.acq_search_scored = (xi.copy(), np.array(u, dtype=float))
+    x_next = np.array(u, dtype=float)
+    x_next[np.where(xi != 0)[0]] = 0.0
+    return x_next
 
 
 def EId_xstar(GP_model, mc_samples):

@@ -24,7 +24,14 @@ __global__ __launch_bounds__(GC::NT, (GC::NT == 512) ? 4 : 2) void dgemm_kernel(
     g.C += (size_t)blockIdx.y * g.strideC;
   }
   const int ntn = (g.N + BN - 1) / BN;
-  const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
+  int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
+  if (g.nt_chunk > 0) {
+    const int ntm = (g.M + BM - 1) / BM, per_chunk = ntm * g.nt_chunk;
+    const int c = blockIdx.x / per_chunk, rem = blockIdx.x - c * per_chunk;
+    mt = ntm - 1 - rem / g.nt_chunk;
+    nt = c * g.nt_chunk + rem % g.nt_chunk;
+    if (nt >= ntn) return;               // the ragged last chunk
+  }
   const int m0 = mt * BM, n0 = nt * BN;
   if (g.lower_only && n0 > m0 + BM - 1) return;
   int kbeg = 0, kend = g.K;
@@ -86,11 +93,15 @@ int launch_cfg(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, hipStre
     ppbo_lds_limit(ctx, (const void*)dgemm_kernel<GC, RC, RC>, (int)lds);
     ppbo_lds_limit(ctx, (const void*)dgemm_kernel<GC, RC, KC>, (int)lds);
   }
-  const dim3 grid(ntm * ntn, g.batch > 1 ? g.batch : 1);
-  if (!transA && !transB) dgemm_kernel<GC, KC, RC><<<grid, GC::NT, lds, s>>>(g);
-  else if (!transA && transB) dgemm_kernel<GC, KC, KC><<<grid, GC::NT, lds, s>>>(g);
-  else if (transA && !transB) dgemm_kernel<GC, RC, RC><<<grid, GC::NT, lds, s>>>(g);
-  else dgemm_kernel<GC, RC, KC><<<grid, GC::NT, lds, s>>>(g);
+  const bool chunked = g.nt_chunk > 0 && g.batch <= 1;
+  const int ntn_grid = chunked ? ((ntn + g.nt_chunk - 1) / g.nt_chunk) * g.nt_chunk : ntn;
+  GemmArgs gg = g;
+  if (!chunked) gg.nt_chunk = 0;
+  const dim3 grid(ntm * ntn_grid, g.batch > 1 ? g.batch : 1);
+  if (!transA && !transB) dgemm_kernel<GC, KC, RC><<<grid, GC::NT, lds, s>>>(gg);
+  else if (!transA && transB) dgemm_kernel<GC, KC, KC><<<grid, GC::NT, lds, s>>>(gg);
+  else if (transA && !transB) dgemm_kernel<GC, RC, RC><<<grid, GC::NT, lds, s>>>(gg);
+  else dgemm_kernel<GC, RC, KC><<<grid, GC::NT, lds, s>>>(gg);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }

@@ -12,6 +12,10 @@ struct GemmArgs {
   int khi_mode;     // 0: K   1: A block-lower-triangular (k < roundup(m0+128, tri_block))   2: k < min(m0,n0)+128
   int klo_mode;     // 0: 0   1: k >= max(m0, n0)   2: k >= n0
   int tri_block;
+  int nt_chunk;     // > 0 (128 x 128-tile configuration, no batch): tiles are walked in chunks of nt_chunk column tiles -- all
+                    // row tiles of a chunk, longest K range first, before the next chunk -- so that the chunk's slice
+                    // of B is re-read from the Infinity Cache instead of HBM once per row tile (the order of
+                    // quadform_kernel); 0: row-tile-major as launched
   int batch;                      // grid.y; operand b lives at base + b*stride (elements); 0/1 = single
   long long strideA, strideB, strideC;
 };

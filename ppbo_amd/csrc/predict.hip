@@ -321,6 +321,171 @@ __global__ __launch_bounds__(256) void line_prior_kernel(const double* __restric
   }
 }
 
+// The data term of a line's G x G predictive covariance, C_b = K*_b' Lambda K*_b + Y_b' Y_b (Y = G K*; gp_model.py:447-450
+// through the Woodbury form of DESIGN 2.4), for one line per workgroup and one slice of the N rows per blockIdx.y.
+// Replaces lam_apply_kernel + two batched 128 x 128-tile GEMMs whose 70 x 70 outputs used 30 % of every tile
+// (1.61 ms of the 4.6 ms of 512 lines x 70 points at N = 2048): the rows are streamed once, 32 at a time, through
+// LDS (next chunk in registers while the current one is multiplied), Lambda is applied while a chunk is staged --
+//   K*' Lambda K* = sum_j k_j b_j' + (its transpose) / 2,  b_j = lam_jj k_j + 2 lam_off,j k_obs(j)  (pseudo rows),
+//                                                          b_obs = lam_obs k_obs,
+// the ONE-SIDED form: a row's b needs only its own row and its star's observation row; the consumer symmetrises --
+// and both products accumulate in the same NT16 x NT16 grid of 16 x 16 MFMA tiles.  out[blockIdx.y][b][G*G].
+// tile t of the NT16 x NT16 grid in the order the wavefronts share them out: SYM walks the lower triangle (mt >= nt)
+// only, row by row
+template <int NT16, bool SYM>
+struct LcTiles {
+  static constexpr int N = SYM ? NT16 * (NT16 + 1) / 2 : NT16 * NT16;
+  static constexpr int mt(int t) {
+    if (!SYM) return t / NT16;
+    int m = 0;
+    while ((m + 1) * (m + 2) / 2 <= t) ++m;
+    return m;
+  }
+  static constexpr int nt(int t) { return SYM ? t - mt(t) * (mt(t) + 1) / 2 : t % NT16; }
+};
+
+// the MFMAs of one k-step over the tiles W, W + 4, ... (compile-time recursion: the fragment indices are constants)
+template <int NT16, bool SYM, int W, int I>
+__device__ __forceinline__ void lc_mfma_k(const double (&fk)[NT16], const double (&fb)[NT16],
+                                          double4_t (&acc)[(LcTiles<NT16, SYM>::N + 3) / 4]) {
+  using T = LcTiles<NT16, SYM>;
+  constexpr int tile = W + 4 * I;
+  if constexpr (tile < T::N) {
+    acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(fk[T::mt(tile)], fb[T::nt(tile)], acc[I], 0, 0, 0);
+    lc_mfma_k<NT16, SYM, W, I + 1>(fk, fb, acc);
+  }
+}
+template <int NT16, bool SYM, int W, int I>
+__device__ __forceinline__ void lc_mfma_y(const double (&fy)[NT16], double4_t (&acc)[(LcTiles<NT16, SYM>::N + 3) / 4]) {
+  using T = LcTiles<NT16, SYM>;
+  constexpr int tile = W + 4 * I;
+  if constexpr (tile < T::N) {
+    acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(fy[T::mt(tile)], fy[T::nt(tile)], acc[I], 0, 0, 0);
+    lc_mfma_y<NT16, SYM, W, I + 1>(fy, acc);
+  }
+}
+
+// one 32-row chunk of line_cov_kernel for wavefront W: its tiles are W, W + 4, ... of the tile list
+template <int NT16, bool SYM, int W, int LDC>
+__device__ __forceinline__ void line_cov_mm(const double* Ks, const double* Bs, const double* Ys, int lk, int lr,
+                                            double4_t (&accK)[(LcTiles<NT16, SYM>::N + 3) / 4],
+                                            double4_t (&accY)[(LcTiles<NT16, SYM>::N + 3) / 4]) {
+#pragma unroll 1
+  for (int kk = 0; kk < 8; ++kk) {          // not unrolled: 3 NT16 fragments per step are live, not 24 NT16
+    const int ko = (4 * kk + lk) * LDC + lr;
+    // this k-step's fragments of all NT16 column blocks, once: every tile of the wavefront draws on them
+    double fk[NT16], fb[NT16], fy[NT16];
+#pragma unroll
+    for (int c = 0; c < NT16; ++c) { fk[c] = Ks[ko + 16 * c]; fb[c] = Bs[ko + 16 * c]; fy[c] = Ys[ko + 16 * c]; }
+    lc_mfma_k<NT16, SYM, W, 0>(fk, fb, accK);
+    lc_mfma_y<NT16, SYM, W, 0>(fy, accY);
+  }
+}
+
+constexpr int LC_MAXROWS = 512;      // rows of one (line, slice) workgroup: their Lambda entries sit in LDS
+
+// SYM (the host picks it when mblk == 32 and the row slices are 32-aligned: every chunk is exactly one star): Lambda K*
+// is formed EXACTLY -- the observation row gets lam_obs k_obs + sum_j lam_off,j k_j from the staged chunk -- so that both
+// products are symmetric and only the tiles of the lower triangle (15 of 25 at G = 70) are computed.
+template <int NT16, bool SYM>
+__global__ __launch_bounds__(256, (NT16 <= 5) ? 2 : 1) void line_cov_kernel(const double* __restrict__ Kt, const double* __restrict__ Y, int ld,
+                                                          int N, int G, int mblk, const double* __restrict__ lam_diag,
+                                                          const double* __restrict__ lam_off, int rows_per_split,
+                                                          double* __restrict__ out, long long out_stride) {
+  using TL = LcTiles<NT16, SYM>;
+  constexpr int CH = 32, LDC = 16 * NT16 + 8, NTILE = TL::N, TPW = (NTILE + 3) / 4;
+  constexpr int NQ = (CH * 16 * NT16 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) double Ks[CH * LDC], Bs[CH * LDC], Ys[CH * LDC];
+  __shared__ double s_ld[LC_MAXROWS], s_lo[LC_MAXROWS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lk = lane >> 4;
+  const int col0 = blockIdx.x * G;
+  const int r_beg = blockIdx.y * rows_per_split;
+  int r_end = r_beg + rows_per_split;
+  if (r_end > N) r_end = N;
+  // two accumulator sets (K*'B and Y'Y): consecutive MFMAs never share an accumulator (a dependent fp64 MFMA issues
+  // every ~138 cycles, an independent one every 64)
+  double4_t accK[TPW], accY[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) { accK[i] = double4_t{0.0, 0.0, 0.0, 0.0}; accY[i] = double4_t{0.0, 0.0, 0.0, 0.0}; }
+  for (int e = t; e < CH * LDC; e += 256) { Ks[e] = 0.0; Bs[e] = 0.0; Ys[e] = 0.0; }    // the padding columns stay zero
+  for (int i = t; i < r_end - r_beg; i += 256) { s_ld[i] = lam_diag[r_beg + i]; s_lo[i] = lam_off[r_beg + i]; }
+  // element q of this thread inside a chunk: (row rq, column gq), fixed for the whole walk (no division per chunk)
+  int rq[NQ], gq[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int e = t + 256 * q;
+    rq[q] = e / G;
+    gq[q] = e - rq[q] * G;
+  }
+  // A chunk is FETCHED by unconditional loads only (addresses clamped into the matrix, values masked when they are
+  // staged): the first version computed lam * k inside per-element guards, which made every one of the NQ elements its
+  // own memory round trip -- 9 dependent round trips per 32-row chunk, 1.0 ms for a pass that is 0.35 ms of MFMA work.
+  double rk[NQ], ro[NQ], ry[NQ];
+  auto fetch = [&](int row0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      int j = row0 + rq[q];
+      j = j < N ? j : N - 1;
+      const int q0 = (j / mblk) * mblk;
+      const size_t c = (size_t)col0 + gq[q];
+      rk[q] = Kt[(size_t)j * ld + c];
+      ro[q] = Kt[(size_t)q0 * ld + c];           // the star's observation row (L2: the same row for the whole star)
+      ry[q] = Y[(size_t)j * ld + c];
+    }
+  };
+  fetch(r_beg);
+  for (int row0 = r_beg; row0 < r_end; row0 += CH) {
+    __syncthreads();                         // the previous chunk's operands are done with (and, first time, s_ld / s_lo are there)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int r = rq[q], j = row0 + r;
+      if (r < CH) {
+        const bool on = j < r_end;
+        const int jl = on ? j - r_beg : 0;
+        const double kv = on ? rk[q] : 0.0;
+        // Lambda row: lam_jj k_j + c lam_off,j k_obs (lam_off is 0 on observation rows); c = 2: the one-sided form,
+        // c = 1 (SYM): the pseudo-observation rows of the exact product, the observation row follows below
+        Ks[r * LDC + gq[q]] = kv;
+        Bs[r * LDC + gq[q]] = on ? s_ld[jl] * kv + (SYM ? 1.0 : 2.0) * s_lo[jl] * ro[q] : 0.0;
+        Ys[r * LDC + gq[q]] = on ? ry[q] : 0.0;
+      }
+    }
+    __syncthreads();
+    if (SYM) {
+      // the chunk is one star, row 0 its observation: B[0][g] += sum_r lam_off,r K[r][g] (31 terms per column)
+      if (t < 16 * NT16) {
+        double sg = 0.0;
+        const int jl0 = row0 - r_beg;
+#pragma unroll 8
+        for (int r = 1; r < CH; ++r) sg += s_lo[jl0 + r] * Ks[r * LDC + t];
+        Bs[t] += sg;
+      }
+      __syncthreads();
+    }
+    if (row0 + CH < r_end) fetch(row0 + CH);
+    // the tile list of a wavefront is a compile-time list (W + 4 i): a run-time tile index would turn the fragment
+    // arrays into dynamically indexed registers (measured: 1.84 ms instead of 0.99)
+    switch (wave) {
+      case 0: line_cov_mm<NT16, SYM, 0, LDC>(Ks, Bs, Ys, lk, lr, accK, accY); break;
+      case 1: line_cov_mm<NT16, SYM, 1, LDC>(Ks, Bs, Ys, lk, lr, accK, accY); break;
+      case 2: line_cov_mm<NT16, SYM, 2, LDC>(Ks, Bs, Ys, lk, lr, accK, accY); break;
+      default: line_cov_mm<NT16, SYM, 3, LDC>(Ks, Bs, Ys, lk, lr, accK, accY); break;
+    }
+  }
+  double* o = out + (size_t)blockIdx.y * out_stride + (size_t)blockIdx.x * G * G;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int tile = wave + 4 * i;
+    if (tile >= NTILE) continue;
+    const int mt = TL::mt(tile), nt = TL::nt(tile);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int g = 16 * mt + lk + 4 * r, h = 16 * nt + lr;
+      if (g < G && h < G) o[g * G + h] = accK[i][r] + accY[i][r];
+    }
+  }
+}
+
 // Monte-Carlo part of EI / varmax on a line (acquisition.py:72-81, :170-178): f = mu + L z for S draws, max over the
 // line, statistics of the maxima.  grid = (lines, draw splits); one workgroup = one line x one slice of the draws.
 //   1. Cholesky of the G x G posterior covariance in LDS (every split of a line repeats it: 70 short steps, and the
@@ -335,7 +500,9 @@ __global__ __launch_bounds__(256) void line_prior_kernel(const double* __restric
 constexpr int MC_MAXG16 = 128;
 __global__ __launch_bounds__(256) void line_mc_kernel(const double* __restrict__ mu, const double* __restrict__ cov,
                                                       int G, const double* __restrict__ z, int S, double mustar,
-                                                      double jitter, int draws_per_split, double* __restrict__ part) {
+                                                      double jitter, int draws_per_split, double* __restrict__ part,
+                                                      const double* __restrict__ cov_parts = nullptr, int n_parts = 0,
+                                                      long long part_stride = 0, int parts_lower_only = 0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int G16 = (G + 15) & ~15, ld = G16 + 2;
   double* Lm = sm;                           // [G16][ld], rows / columns >= G zero
@@ -343,10 +510,22 @@ __global__ __launch_bounds__(256) void line_mc_kernel(const double* __restrict__
   double* red = mus + G16;                   // [3][4]
   const double* c = cov + (size_t)blockIdx.x * G * G;
   const double* m = mu + (size_t)blockIdx.x * G;
+  // cov_parts: the data term K*' Lambda K* + Y'Y as line_cov_kernel leaves it -- n_parts row-split slabs per line, the
+  // Lambda part in its one-sided form -- added here in slab order
+  const double* cp = cov_parts ? cov_parts + (size_t)blockIdx.x * G * G : nullptr;
   for (int e = threadIdx.x; e < G16 * ld; e += blockDim.x) {
     const int g = e / ld, h = e - g * ld;
-    // symmetrise (the two GEMM contributions are symmetric only up to rounding)
-    Lm[e] = (g < G && h < G) ? 0.5 * (c[g * G + h] + c[h * G + g]) + ((g == h) ? jitter : 0.0) : 0.0;
+    double v = 0.0;
+    if (g < G && h < G) {
+      double a = c[g * G + h], b = c[h * G + g];
+      // parts_lower_only: the slabs are exactly symmetric and hold the 16 x 16 tiles of the lower triangle only
+      const bool up = parts_lower_only && (g >> 4) < (h >> 4);
+      const int ia = up ? h * G + g : g * G + h, ib = (parts_lower_only && !up && (g >> 4) > (h >> 4)) ? g * G + h : h * G + g;
+      for (int k = 0; k < n_parts; ++k) { a += cp[(size_t)k * part_stride + ia]; b += cp[(size_t)k * part_stride + ib]; }
+      // symmetrise (the contributions are symmetric only up to rounding; line_cov_kernel's Lambda term only after this)
+      v = 0.5 * (a + b) + ((g == h) ? jitter : 0.0);
+    }
+    Lm[e] = v;
   }
   for (int g = threadIdx.x; g < G16; g += blockDim.x) mus[g] = (g < G) ? m[g] : -INFINITY;
   __syncthreads();
@@ -720,31 +899,63 @@ int ppbo_predict_cov(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc,
   return ppbo_gemm_launch(ctx, c, 1, 0, s);
 }
 
-int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, int B, int G, double shrink,
-                  const double* d_z, int S, double mustar, double jitter, double* d_ei, double* d_varmax,
-                  void* stream) {
-  PPBO_ENTER(ctx);
+}  // extern "C"
+
+namespace {
+
+// grid[b][g][:] = alpha_(b)[g] * xi[b][:] + x[b][:]: the G points of line b (what FeedbackProcessing.xi_grid returns with
+// is_scaled = True, src/feedback_processing.py:57-107, for abscissae alpha that the host has drawn); per_line = 0: one
+// shared abscissa vector alpha[G] (common random numbers across lines), 1: alpha[B][G]
+__global__ __launch_bounds__(256) void line_grid_kernel(const double* __restrict__ xi, const double* __restrict__ x,
+                                                        const double* __restrict__ alpha, int per_line, int B, int G,
+                                                        int D, double* __restrict__ grid) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)B * G * D) return;
+  const int d = (int)(e % D);
+  const long long bg = e / D;
+  const int g = (int)(bg % G), b = (int)(bg / G);
+  const double a = alpha[per_line ? (size_t)b * G + g : g];
+  grid[e] = a * xi[(size_t)b * D + d] + x[(size_t)b * D + d];
+}
+
+// EI / varmax of B lines whose grid points are either given (d_grid) or formed on the device from (xi, x, alpha)
+int line_acq_impl(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, const double* d_xi, const double* d_x,
+                  const double* d_alpha, int alpha_per_line, int B, int G, double shrink, const double* d_z, int S,
+                  double mustar, double jitter, double* d_ei, double* d_varmax, hipStream_t s) {
   if (int rc = check_model(ctx, model)) return rc;
-  PPBO_REQUIRE(ctx, d_grid && d_z && B > 0 && G > 0 && G <= 128 && S > 0, "line arguments (G <= 128)");
+  PPBO_REQUIRE(ctx, (d_grid || (d_xi && d_x && d_alpha)) && d_z && B > 0 && G > 0 && G <= 128 && S > 0,
+               "line arguments (G <= 128)");
   PPBO_REQUIRE(ctx, model->d_G && model->d_lam_diag && model->d_lam_off, "model G/Lambda");
-  hipStream_t s = (hipStream_t)stream;
   const int N = model->N, mblk = model->m + 1, n_q = N / mblk, D = model->D;
   const KernParams p = make_kern_params(model->kernel_id, model->theta);
   const int Bc_max = (B < 512) ? B : 512;
   const int ld = ((Bc_max * G) + 1) & ~1;
-  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_KSTAR, (size_t)3 * N * ld * sizeof(double));
+  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_KSTAR, (size_t)2 * N * ld * sizeof(double));
   if (!ws) return (int)hipErrorOutOfMemory;
   double* Kt = ws;
-  double* Z = ws + (size_t)N * ld;
-  double* Y = ws + (size_t)2 * N * ld;
+  double* Y = ws + (size_t)N * ld;
+  double* gridws = nullptr;
+  if (!d_grid) {
+    gridws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH, (size_t)Bc_max * G * D * sizeof(double));
+    if (!gridws) return (int)hipErrorOutOfMemory;
+  }
   const int n_split = pick_split(Bc_max * G, n_q);
   const int q_per_split = (n_q + n_split - 1) / n_split;
   const int n_split_eff = (n_q + q_per_split - 1) / q_per_split;
+  // row slices of the covariance's data term: enough (line, slice) workgroups for every CU to hold several
+  int cov_splits = (1024 + Bc_max - 1) / Bc_max;
+  if (cov_splits < (N + LC_MAXROWS - 1) / LC_MAXROWS) cov_splits = (N + LC_MAXROWS - 1) / LC_MAXROWS;   // <= LC_MAXROWS rows per slice
+  if (cov_splits > (N + 31) / 32) cov_splits = (N + 31) / 32;
+  if (cov_splits < 1) cov_splits = 1;
+  const int cov_rows = ((((N + cov_splits - 1) / cov_splits) + 31) / 32) * 32;
+  cov_splits = (N + cov_rows - 1) / cov_rows;
   double* part = (double*)ppbo_workspace(
-      ctx, ppbo_ctx::WS_PART, ((size_t)(n_split_eff + 1) * Bc_max * G + (size_t)Bc_max * G * G) * sizeof(double));
+      ctx, ppbo_ctx::WS_PART,
+      ((size_t)(n_split_eff + 1) * Bc_max * G + (size_t)(1 + cov_splits) * Bc_max * G * G) * sizeof(double));
   if (!part) return (int)hipErrorOutOfMemory;
   double* mu = part + (size_t)n_split_eff * Bc_max * G;
   double* cov = mu + (size_t)Bc_max * G;
+  double* cov_parts = cov + (size_t)Bc_max * G * G;
   const int G16 = (G + 15) & ~15;
   const size_t mc_lds = ((size_t)G16 * (G16 + 2) + G16 + 16) * sizeof(double);   // G = 128: 134 KB of the CU's 160 KB
   if (mc_lds > 64 * 1024) ppbo_lds_limit(ctx, (const void*)line_mc_kernel, (128 * 130 + 128 + 16) * (int)sizeof(double));
@@ -759,7 +970,16 @@ int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
   for (int b0 = 0; b0 < B; b0 += Bc_max) {
     const int Bc = (B - b0 < Bc_max) ? (B - b0) : Bc_max;
     const int M = Bc * G;
-    const double* xg = d_grid + (size_t)b0 * G * D;
+    const double* xg;
+    if (d_grid) {
+      xg = d_grid + (size_t)b0 * G * D;
+    } else {
+      const long long ne = (long long)Bc * G * D;
+      line_grid_kernel<<<(unsigned)((ne + 255) / 256), 256, 0, s>>>(d_xi + (size_t)b0 * D, d_x + (size_t)b0 * D,
+                                                                    alpha_per_line ? d_alpha + (size_t)b0 * G : d_alpha,
+                                                                    alpha_per_line, Bc, G, D, gridws);
+      xg = gridws;
+    }
     dispatch_kstar(model, xg, M, Kt, ld, part, nullptr, q_per_split, n_split_eff, false, s);
     score_kernel<<<score_blocks(M), SC_THREADS, 0, s>>>(part, n_split_eff, nullptr, nullptr, 0, M, 0.0, PPBO_SCORE_MEAN,
                                                         0.0, 0, mu, nullptr, nullptr, nullptr);
@@ -768,27 +988,66 @@ int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
       case PPBO_KERNEL_RQ: line_prior_kernel<PPBO_KERNEL_RQ><<<Bc, 256, 0, s>>>(xg, G, D, p, shrink, cov); break;
       default: line_prior_kernel<PPBO_KERNEL_CAMPHOR><<<Bc, 256, 0, s>>>(xg, G, D, p, shrink, cov); break;
     }
-    lam_apply_kernel<<<dim3((M + 127) / 128, n_q), 128, 0, s>>>(Kt, ld, N, M, mblk, model->d_lam_diag,
-                                                                model->d_lam_off, Z);
     PPBO_LAUNCH_CHECK(ctx);
     GemmArgs y{};  // Y = G K*
     y.A = model->d_G; y.lda = N; y.B = Kt; y.ldb = ld; y.C = Y; y.ldc = ld;
     y.M = N; y.N = M; y.K = N; y.alpha = 1.0; y.beta = 0.0; y.khi_mode = 1; y.tri_block = mblk;
+    y.nt_chunk = 64;      // 64 column tiles (8192 points, 134 MB of K*) through all row tiles, heaviest first, then the next 64
     if (int rc = ppbo_gemm_launch(ctx, y, 0, 0, s)) return rc;
-    GemmArgs c1{};  // cov_b += K*_b' Z_b   (batched over lines)
-    c1.A = Kt; c1.lda = ld; c1.B = Z; c1.ldb = ld; c1.C = cov; c1.ldc = G;
-    c1.M = G; c1.N = G; c1.K = N; c1.alpha = 1.0; c1.beta = 1.0; c1.tri_block = 1;
-    c1.batch = Bc; c1.strideA = G; c1.strideB = G; c1.strideC = (long long)G * G;
-    if (int rc = ppbo_gemm_launch(ctx, c1, 1, 0, s)) return rc;
-    GemmArgs c2 = c1;  // cov_b += Y_b' Y_b
-    c2.A = Y; c2.B = Y;
-    if (int rc = ppbo_gemm_launch(ctx, c2, 1, 0, s)) return rc;
-    line_mc_kernel<<<dim3(Bc, nsplit), 256, mc_lds, s>>>(mu, cov, G, d_z, S, mustar, jitter, draws_per_split, mc_part);
+    // data term of every line's covariance: K*' Lambda K* + Y'Y, one workgroup per (line, row slice)
+    const bool sym = (mblk == 32) && (cov_rows % 32 == 0);
+    {
+      const dim3 cg(Bc, cov_splits);
+      const long long pst = (long long)Bc_max * G * G;
+      // sym: every chunk of 32 rows is exactly one star: the symmetric form (lower-triangle tiles only)
+#define LC_LAUNCH(NT)                                                                                                   \
+  do {                                                                                                                  \
+    if (sym) line_cov_kernel<NT, true><<<cg, 256, 0, s>>>(Kt, Y, ld, N, G, mblk, model->d_lam_diag, model->d_lam_off,   \
+                                                          cov_rows, cov_parts, pst);                                    \
+    else line_cov_kernel<NT, false><<<cg, 256, 0, s>>>(Kt, Y, ld, N, G, mblk, model->d_lam_diag, model->d_lam_off,      \
+                                                       cov_rows, cov_parts, pst);                                       \
+  } while (0)
+      switch ((G + 15) / 16) {
+        case 1: LC_LAUNCH(1); break;
+        case 2: LC_LAUNCH(2); break;
+        case 3: LC_LAUNCH(3); break;
+        case 4: LC_LAUNCH(4); break;
+        case 5: LC_LAUNCH(5); break;
+        case 6: LC_LAUNCH(6); break;
+        case 7: LC_LAUNCH(7); break;
+        default: LC_LAUNCH(8); break;
+      }
+#undef LC_LAUNCH
+    }
+    line_mc_kernel<<<dim3(Bc, nsplit), 256, mc_lds, s>>>(mu, cov, G, d_z, S, mustar, jitter, draws_per_split, mc_part,
+                                                         cov_parts, cov_splits, (long long)Bc_max * G * G, sym ? 1 : 0);
     mc_finish_kernel<<<(Bc + 255) / 256, 256, 0, s>>>(mc_part, Bc, nsplit, S, d_ei ? d_ei + b0 : nullptr,
                                                       d_varmax ? d_varmax + b0 : nullptr);
     PPBO_LAUNCH_CHECK(ctx);
   }
   return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, int B, int G, double shrink,
+                  const double* d_z, int S, double mustar, double jitter, double* d_ei, double* d_varmax,
+                  void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_grid != nullptr, "d_grid");
+  return line_acq_impl(ctx, model, d_grid, nullptr, nullptr, nullptr, 0, B, G, shrink, d_z, S, mustar, jitter, d_ei,
+                       d_varmax, (hipStream_t)stream);
+}
+
+int ppbo_line_acq_xi(ppbo_ctx* ctx, const ppbo_model* model, const double* d_xi, const double* d_x,
+                     const double* d_alpha, int alpha_per_line, int B, int G, double shrink, const double* d_z, int S,
+                     double mustar, double jitter, double* d_ei, double* d_varmax, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_xi && d_x && d_alpha, "xi / x / alpha");
+  return line_acq_impl(ctx, model, nullptr, d_xi, d_x, d_alpha, alpha_per_line != 0, B, G, shrink, d_z, S, mustar,
+                       jitter, d_ei, d_varmax, (hipStream_t)stream);
 }
 
 int ppbo_randn(ppbo_ctx* ctx, uint64_t seed, double* d_out, int64_t n, void* stream) {

@@ -510,6 +510,26 @@ class Engine:
         self._check(rc, "ppbo_line_acq")
         return ei, vm
 
+    def line_acq_xi(self, post: Posterior, xis, xs, alphas, z, mustar, shrink=SHRINKAGE, jitter=0.0):
+        """EI and varmax of the B lines {alpha * xis[b] + xs[b]} (ppbo_line_acq_xi): the grid points are formed on the
+        device.  alphas: [G] (shared by all lines) or [B, G]."""
+        xis, xs, alphas, z = self.dev(xis), self.dev(xs), self.dev(alphas), self.dev(z)
+        B, D = xis.shape
+        if xs.shape != (B, D):
+            raise ValueError("line_acq_xi: xis and xs must both be [B, D]")
+        per_line = alphas.dim() == 2
+        G = alphas.shape[-1]
+        if per_line and alphas.shape[0] != B:
+            raise ValueError("line_acq_xi: per-line abscissae must be [B, G]")
+        S = z.shape[0]
+        md = self._model(post, True)
+        ei, vm = self.empty(B), self.empty(B)
+        rc = self.lib.ppbo_line_acq_xi(self.ctx, C.byref(md), _ptr(xis), _ptr(xs), _ptr(alphas), int(per_line), B, G,
+                                       float(shrink), _ptr(z), S, float(mustar), float(jitter), _ptr(ei), _ptr(vm),
+                                       self._stream())
+        self._check(rc, "ppbo_line_acq_xi")
+        return ei, vm
+
     # ---- RFF -------------------------------------------------------------------------
     def rff_project(self, X, W, b, sigma_f, out=None):
         X, W, b = self.dev(X), self.dev(W), self.dev(b).reshape(-1)

@@ -60,9 +60,15 @@ def test_joint_searches_reach_the_dense_sweeps_top_decile(golden, name, fn):
     fixed = gp.xstar.copy() if fn == "maximize_EI_fixed_x" else None
 
     def lines_of(U):
+        if fixed is not None:
+            # the REFERENCE's objective (src/acquisition.py:109-113): EI(xi_, xstar), xi_ = xstar overwritten on xi_dims,
+            # the full xstar as x -- not the (xi, x) pair the function returns (:124-131)
+            xis = np.tile(fixed, (len(U), 1))
+            xis[:, xi_dims] = U[:, :2]
+            return xis, np.tile(fixed, (len(U), 1))
         xis, xs = np.zeros((len(U), D)), np.zeros((len(U), D))
         xis[:, xi_dims] = U[:, :2]
-        xs[:, x_dims] = U[:, 2:] if fixed is None else fixed[x_dims]
+        xs[:, x_dims] = U[:, 2:]
         return xis, xs
 
     k = 2 if fixed is not None else D
@@ -72,7 +78,11 @@ def test_joint_searches_reach_the_dense_sweeps_top_decile(golden, name, fn):
     assert np.all(xi[x_dims] == 0) and np.all(x[xi_dims] == 0) and np.all(xi[xi_dims] > 0)
     if fixed is not None:
         assert np.allclose(x[x_dims], fixed[x_dims])
-    got = score(xi, x)
+        # scored line = the reference's: direction xstar with the searched coordinates written in, through the full xstar
+        sxi, sx = gp.acq_search_scored
+        assert np.array_equal(sx, fixed) and np.array_equal(sxi[x_dims], fixed[x_dims])
+        assert np.allclose(sxi[xi_dims], xi[xi_dims], atol=1e-6)
+    got = score(*gp.acq_search_scored)
     p90, best = np.percentile(vals, 90), vals.max()
     log = gp.acq_search_log
     print(f"{name} {fn}: search {got:.4e}  sweep p50 {np.median(vals):.4e} p90 {p90:.4e} max {best:.4e}  rounds {log}")
@@ -90,18 +100,19 @@ def test_varmax_given_xi_reaches_the_dense_sweeps_top_decile(golden, name):
     D = gp.D
     xi = np.zeros(D)
     xi[0] = 1.0
-    free = list(range(1, D))
 
     def lines_of(U):
-        xs = np.zeros((len(U), D))
-        xs[:, free] = U
-        return np.tile(xi, (len(U), 1)), xs
+        # the REFERENCE's domain (src/acquisition.py:208-214): varmax(xi, x) with ALL D coordinates of x free; the
+        # coordinates on xi's support are zeroed only in the returned x (:216-217)
+        return np.tile(xi, (len(U), 1)), np.asarray(U, dtype=float)
 
-    vals, score, se = _sweep(gp, st, lines_of, D - 1, "vm", seed=21)
+    vals, score, se = _sweep(gp, st, lines_of, D, "vm", seed=21)
     np.random.seed(6)
     x = acq.maximize_varmax_given_xi(xi, gp, st)
     assert x[0] == 0.0 and np.all((x >= 0) & (x <= 1))
-    got = score(xi, x)
+    sxi, sx = gp.acq_search_scored
+    assert np.array_equal(sxi, xi) and np.array_equal(sx[1:], x[1:]) and 0.0 <= sx[0] <= 1.0
+    got = score(sxi, sx)
     print(f"{name} maximize_varmax_given_xi: search {got:.4e}  sweep p50 {np.median(vals):.4e} p90 {np.percentile(vals, 90):.4e} "
           f"max {vals.max():.4e}  yardstick s.e. {np.median(se):.1e}")
     # on c2 this landscape is flat to within a few per cent (p90 / p50 ~ 1.03), the size of the yardstick's own

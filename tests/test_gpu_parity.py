@@ -437,6 +437,23 @@ def test_pipeline_general_m_vs_oracle(eng, m, n_q, D, kernel):
     mu1, cov1 = eng.predict_cov(post, Xc[:70])
     _, cov0 = orc.mu_sigma_pred(Xc[:70], X, th, Sinv0, f0, P0, kernel, faithful=False, A=A0)
     assert np.abs(host(cov1) - cov0).max() <= 1e-7 * th[2] ** 2
+    # the line acquisitions at this star size: the covariance's data term takes the ONE-SIDED Lambda form of
+    # line_cov_kernel (stars do not coincide with its 32-row chunks) -- against the oracle on the oracle's covariance
+    rng = np.random.default_rng(6)
+    B, G, Sd = 7, 70, 96
+    xis = np.eye(D)[rng.integers(0, D, B)]
+    xs = rng.random((B, D)) * (xis == 0)
+    al = np.sort(np.clip(np.linspace(0.005, 0.995, G) + rng.normal(0, 0.01, (B, G)), 0, 1), axis=1)
+    z = rng.standard_normal((Sd, G))
+    mustar, jit = float(mu0.max()), 1e-9 * th[2] ** 2
+    ei, vm = eng.line_acq_xi(post, xis, xs, al, z, mustar, jitter=jit)
+    for b in range(B):
+        grid = al[b][:, None] * xis[b][None, :] + xs[b][None, :]
+        mu_b, cov_b = orc.mu_sigma_pred(grid, X, th, Sinv0, f0, P0, kernel, faithful=False, A=A0)
+        e0 = orc.line_ei(mu_b, cov_b, z, mustar, jitter=jit)
+        v0 = orc.line_varmax(mu_b, cov_b, z, jitter=jit)
+        assert abs(float(host(ei)[b]) - e0) <= 1e-6 * max(abs(e0), 1e-3 * th[2])
+        assert abs(float(host(vm)[b]) - v0) <= 1e-5 * max(abs(v0), 1e-6 * th[2] ** 2)
 
 
 def test_c5_size_camphor_properties(eng):
@@ -762,3 +779,30 @@ def test_factor_triangular_inverse_and_inverse_together(eng, N):
     # and the next call on the same ctx is unaffected
     Ai2 = host(eng.pd_inverse(A))
     assert np.array_equal(Ai2, Ai)
+
+
+@pytest.mark.parametrize("name", [n for n in ("smoke", "c2", "c3") if n in ALL])
+@pytest.mark.parametrize("per_line", [False, True])
+def test_line_acq_xi_forms_the_grid_on_the_device(eng, golden, name, per_line):
+    """ppbo_line_acq_xi(xi, x, alpha) = ppbo_line_acq on the grid alpha * xi + x built by the host
+    (FeedbackProcessing.xi_grid with is_scaled, src/feedback_processing.py:57-107): same bits, with one abscissa
+    vector shared by all lines and with one per line; more lines than one chunk of 512 included."""
+    g = golden(name)
+    post, _ = _posterior(eng, g)
+    D = int(g["D"])
+    rng = np.random.default_rng(7)
+    B, G, S = (700 if name == "smoke" else 96), 70, 64
+    xis = rng.random((B, D)) * (rng.random((B, D)) < 0.5)
+    xis[np.arange(B), rng.integers(0, D, B)] = 1.0
+    xs = rng.random((B, D)) * (xis == 0)
+    base = np.linspace(0.005, 0.995, G)
+    alphas = np.sort(np.clip(base + rng.normal(0, 0.01, (B, G) if per_line else G), 0.0, 1.0), axis=-1)
+    grid = (alphas[:, :, None] if per_line else alphas[None, :, None]) * xis[:, None, :] + xs[:, None, :]
+    z = rng.standard_normal((S, G))
+    mustar = float(np.max(g["mu"]))
+    jit = 1e-10 * float(g["theta"][2]) ** 2
+    ei0, vm0 = eng.line_acq(post, grid, z, mustar, jitter=jit)
+    ei1, vm1 = eng.line_acq_xi(post, xis, xs, alphas, z, mustar, jitter=jit)
+    assert np.array_equal(host(ei0), host(ei1)) and np.array_equal(host(vm0), host(vm1))
+    with pytest.raises(ValueError):
+        eng.line_acq_xi(post, xis, xs[:-1], alphas, z, mustar)

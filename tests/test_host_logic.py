@@ -252,3 +252,90 @@ def test_create_X_and_update_X_agree():
     three.create_X()                                    # the reference's two-step form (:37-38)
     three.create_indices_bookkeeping()
     assert np.array_equal(three.X, one.X)
+
+
+# ---- a-15: the objectives the outer searches score are the reference's own (no GPU: the line scorer is a stub) --------
+class _StubEngine:
+    def randn(self, seed, *shape):
+        return np.zeros(shape)
+
+
+class _StubModel:
+    def __init__(self, D):
+        self.D, self.eng = D, _StubEngine()
+        self.xstar = np.linspace(0.15, 0.85, D)
+        self.mustar, self.theta = 0.0, [0.1, 0.3, 0.5]
+
+
+def _recording_scorer(monkeypatch):
+    from ppbo_amd import acquisition as acq
+    seen = []
+
+    def fake(xis, xs, GP_model, mc_samples, z=None, alphas=None):
+        xis, xs = np.atleast_2d(xis), np.atleast_2d(xs)
+        seen.append((xis.copy(), xs.copy()))
+        v = -((xis - 0.3) ** 2).sum(axis=1) - ((xs - 0.6) ** 2).sum(axis=1)        # any smooth landscape
+        return v, v
+
+    monkeypatch.setattr(acq, "_line_scores", fake)
+    return seen
+
+
+def test_maximize_EI_fixed_x_scores_the_references_objective(monkeypatch):
+    """src/acquisition.py:109-131: BO varies xi on xi_dims only; the objective is EI(xi_, xstar) with xi_ = xstar.copy(),
+    xi_[xi_dims] = candidate, and the FULL xstar as x.  The pair that is RETURNED is a different line: xi zero off
+    xi_dims, x = xstar off xi_dims and zero on them."""
+    from ppbo_amd import acquisition as acq
+    from ppbo_amd.ppbo_settings import PPBO_settings
+    D, xi_dims = 5, [1, 3]
+    gp = _StubModel(D)
+    st = PPBO_settings(D=D, bounds=((0, 1),) * D, xi_acquisition_function="EI-FIXEDX", verbose=False)
+    seen = _recording_scorer(monkeypatch)
+    np.random.seed(0)
+    xi, x = acq.maximize_EI_fixed_x(xi_dims, gp, st)
+    x_dims = [0, 2, 4]
+    assert seen
+    for xis, xs in seen:
+        assert np.array_equal(xs, np.tile(gp.xstar, (len(xs), 1)))                  # x = xstar, every coordinate
+        assert np.array_equal(xis[:, x_dims], np.tile(gp.xstar[x_dims], (len(xis), 1)))   # xi keeps xstar off xi_dims
+        assert np.all((xis[:, xi_dims] >= 0) & (xis[:, xi_dims] <= 1))
+    assert np.all(xi[x_dims] == 0) and np.all(x[xi_dims] == 0) and np.allclose(x[x_dims], gp.xstar[x_dims])
+    assert np.allclose(gp.acq_search_scored[0][xi_dims], xi[xi_dims], atol=1e-6)
+
+
+def test_maximize_varmax_given_xi_searches_the_whole_box(monkeypatch):
+    """src/acquisition.py:208-218: the objective is varmax(xi, x) over ALL D coordinates of x; the coordinates on xi's
+    support are zeroed in the result, not in the search."""
+    from ppbo_amd import acquisition as acq
+    from ppbo_amd.ppbo_settings import PPBO_settings
+    D = 4
+    gp = _StubModel(D)
+    st = PPBO_settings(D=D, bounds=((0, 1),) * D, xi_acquisition_function="COORDINATE-VARMAX", verbose=False)
+    xi = np.array([0.0, 1.0, 0.0, 0.0])
+    seen = _recording_scorer(monkeypatch)
+    np.random.seed(1)
+    x = acq.maximize_varmax_given_xi(xi, gp, st)
+    assert any(np.any(xs[:, 1] != 0.0) for _, xs in seen)                          # x varies on xi's support too
+    assert all(np.array_equal(xis, np.tile(xi, (len(xis), 1))) for xis, _ in seen)
+    assert x[1] == 0.0 and np.all(x[[0, 2, 3]] > 0)
+    assert gp.acq_search_scored[1][1] != 0.0 and np.array_equal(gp.acq_search_scored[1][[0, 2, 3]], x[[0, 2, 3]])
+
+
+def test_noisy_alpha_rows_follow_the_reference_recipe():
+    """70 abscissae per line: linspace(0.005, 0.995) + N(0, 0.01), clipped to [0, 1], sorted, all distinct
+    (src/feedback_processing.py:57-74 with is_scaled); B lines in one call consume the stream like B calls of one."""
+    from ppbo_amd import acquisition as acq
+    np.random.seed(4)
+    a = acq._noisy_alpha_rows(300)
+    assert a.shape == (300, 70) and np.all(np.diff(a, axis=1) > 0) and a.min() >= 0.0 and a.max() <= 1.0
+    assert np.abs(a - np.linspace(0.005, 0.995, 70)).max() < 0.06
+    # the first pass is ONE block of B x 70 normals, row b = what the b-th sequential xi_grid call would have drawn;
+    # only rows in which two values were clipped onto the same boundary (a redraw: ~2 % of the rows) differ
+    np.random.seed(4)
+    first = np.sort(np.clip(np.linspace(0.005, 0.995, 70) + np.random.normal(0.0, 0.01, (300, 70)), 0.0, 1.0), axis=1)
+    clean = ~(np.diff(first, axis=1) == 0.0).any(axis=1)
+    assert clean.sum() >= 280 and np.array_equal(a[clean], first[clean])
+    np.random.seed(4)
+    k = int(np.argmin(clean)) if not clean.all() else 300          # sequential calls agree up to the first redraw
+    b = np.stack([acq._noisy_alpha_rows(1)[0] for _ in range(k)])
+    assert np.array_equal(a[:k], b)
