@@ -97,18 +97,23 @@ def cpu_baseline(g, M_sample, seconds_budget=25.0, gpu_check=None):
 
 
 
-def per_query_breakdown(torch, reps=5):
-    """One PPBO iteration on the C2 shape (Hartmann6-like: D = 6, N = 512, theta = [0.001, 0.26, 0.1]) through the
-    drop-in objects, phase by phase (ms, median of `reps`): what GPModel.update_model + next_query cost per query
-    (ppbo_numerical_main.py:86-92,107-124).  fit_cold = update_Sigma + update_Sigma_inv + update_fMAP (a fresh prior
-    draw, the reference's default) + posterior; fit_incremental = the same after ONE appended query with
-    GPModel(incremental=True) (bordered Sigma^-1, warm start); mu_star = ONE trial of the device-resident search
-    (the reference's default is 3 per iteration); next_query = EI-EXT-FAST (D lines, 150 draws) and the EI joint
-    search (BO_maxiter = 20)."""
+def per_query_breakdown(torch, cfg="c2", reps=5):
+    """One PPBO iteration on the shape of BASELINE config `cfg` (c2: D = 6, N = 512; c3: D = 20, N = 2048 -- the
+    metric's shape) through the drop-in objects, phase by phase (ms, median of `reps`): what GPModel.update_model +
+    next_query cost per query (ppbo_numerical_main.py:86-92,107-124).
+      update_model_fit   the default update (one prior-draw start) = ONE ppbo_gp_fit call: Sigma, factor, inverse,
+                         whitened f_MAP search, posterior (src/gp_model.py:91-117, without mu_star)
+      fit_incremental    the same after ONE appended query with GPModel(incremental=True) (bordered factor, warm start)
+      mu_star            ONE trial of the device-resident search (the reference's default is 3 per iteration)
+      next_query_*       every strategy family of src/acquisition.py:9-65: EI-EXT-FAST (D lines), EI-EXT (50 D lines),
+                         EI / EXR (joint searches, BO_maxiter = 20), EI-VARMAX (50 D lines + the x search)
+      hsampler_cycle     Hsampler(gp, F): basis, Phi(X), omega_MAP, one posterior sample and its maximiser
+                         (src/random_fourier_sampler.py; the sequence of ppbo_numerical_main.py:279-292)"""
     from ppbo_amd.acquisition import next_query
     from ppbo_amd.gp_model import GPModel
     from ppbo_amd.ppbo_settings import PPBO_settings
-    g = synth_model_inputs("c2")
+    from ppbo_amd.random_fourier_sampler import Hsampler
+    g = synth_model_inputs(cfg)
     D, m = int(g["D"]), int(g["m"])
 
     def model(acq, n_q, incremental=False):
@@ -133,29 +138,35 @@ def per_query_breakdown(torch, reps=5):
 
     n_q = g["X_obs"].shape[0]
     gp, st = model("EI-EXT-FAST", n_q)
-
-    def fit_cold():
-        gp.update_Sigma(gp.theta)
-        gp.update_Sigma_inv(gp.theta)
-        gp.update_fMAP()
-        gp._post = gp.eng.posterior(gp._dX, gp.theta, gp.kernel.__name__, gp._dSigma_inv, gp.eng.dev(gp.fMAP), gp.m)
-        gp._post_mean = gp._post
-
     gp.set_theta()
     np.random.seed(1)
-    fit_cold()
-    out = {"shape": f"C2: N={gp.N}, D={D}, m={m}, theta={list(map(float, g['theta']))}"}
-    out["fit_cold_ms"] = med(fit_cold)
-    out["fit_cold_lbfgs_evals"] = gp.fit_log[-1]["lbfgs_evals"]
+    assert gp._fit_fused()
+    out = {"shape": f"{cfg}: N={gp.N}, D={D}, m={m}, theta={list(map(float, g['theta']))}"}
+    out["update_model_fit_ms"] = med(lambda: gp._fit_fused())
+    out["update_model_fit_lbfgs_evals"] = gp.fit_log[-1]["lbfgs_evals"]
     gp.mu_star(mustar_finding_trials=1)
     out["mu_star_ms_per_trial"] = med(lambda: gp.mu_star(mustar_finding_trials=4)) / 4.0
     gp.xstar, gp.mustar, gp.xstars_local = gp.mu_star()
-    next_query(st, gp)
-    out["next_query_EI_EXT_FAST_ms"] = med(lambda: next_query(st, gp))
-    st.xi_acquisition_function = "EI"
-    st.xi_dims_prev_iter = [0, 1]
-    next_query(st, gp)
-    out["next_query_EI_search_ms"] = med(lambda: next_query(st, gp), 3)
+    for acq, key in (("EI-EXT-FAST", "next_query_EI_EXT_FAST_ms"), ("EI-EXT", "next_query_EI_EXT_ms"),
+                     ("EI", "next_query_EI_search_ms"), ("EXR", "next_query_EXR_search_ms"),
+                     ("EI-VARMAX", "next_query_EI_VARMAX_ms")):
+        sa = PPBO_settings(D=D, bounds=tuple(map(tuple, g["bounds"])), xi_acquisition_function=acq,
+                           theta_initial=list(map(float, g["theta"])), m=m, verbose=False, kernel=str(g["kernel"]))
+        next_query(sa, gp)
+        out[key] = med(lambda: next_query(sa, gp), 3)
+    if str(g["kernel"]) == "SE_kernel":          # the reference has a spectral basis for the SE kernel only
+        F = 4096 if cfg == "c3" else 1000
+
+        def cycle():
+            hs = Hsampler(gp, F)
+            hs.generate_basis()
+            hs.update_phi_X()
+            hs.update_omega_MAP()
+            hs.update_covariancematrix()
+            hs.sample_xstar()
+        cycle()
+        out["hsampler_cycle_ms"] = med(cycle, 3)
+        out["hsampler_features"] = F
     # incremental: fit n_q - 1 queries, then time the update that appends the last one
     ts = []
     for _ in range(3):
@@ -219,6 +230,9 @@ def main():
                     help="initialise torch.distributed (nccl) and run the collective path even with ONE rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the RFF / line-acquisition side measurements")
+    ap.add_argument("--no-precision-report", action="store_true",
+                    help="skip the fp64 / fp32-K* report on the fixture's 512 candidates (with --no-secondary and "
+                         "--no-cpu-baseline every kernel row of a rocprofv3 --stats run is then ONE launch shape)")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -539,12 +553,28 @@ def main():
         rngl = np.random.default_rng(6)
         al = np.linspace(0.005, 0.995, G)
         xs = rngl.random((B, D))
-        grid = np.repeat(xs[:, None, :], G, axis=1)
         dsel = np.arange(B) % D
-        grid[np.arange(B)[:, None], np.arange(G)[None, :], dsel[:, None]] = al[None, :]
-        gridd = eng.dev(grid)
         z = eng.dev(rngl.standard_normal((S, G)))
-        t_line = timed(lambda: eng.line_acq(post, gridd, z, mustar, jitter=1e-10 * float(th[2]) ** 2), 3)
+        xi_l, x_l = np.eye(D)[dsel], xs.copy()
+        x_l[np.arange(B), dsel] = 0.0
+        xi_d, x_d, al_d = eng.dev(xi_l), eng.dev(x_l), eng.dev(al)
+        line_fn = lambda: eng.line_acq_xi(post, xi_d, x_d, al_d, z, mustar, jitter=1e-10 * float(th[2]) ** 2)
+        t_line = timed(line_fn, 3)
+        eng.profile(True)
+        for _ in range(3):
+            line_fn()
+        torch.cuda.synchronize()
+        lk = {k: eng.profile_read(k) for k in ("line_kstar", "line_y", "line_cov", "line_mc")}
+        eng.profile(False)
+        Ml = B * G
+        mb = m + 1
+        # executed MFMA flops: Y = G K* over 128-row tiles cut at the end of the tile's last star (the GEMM's K limit),
+        # and the covariance's data term: (lower-triangle tiles of the ceil(G/16)^2 grid) x 2 products x N rows
+        y_flops = sum(2.0 * 128 * Ml * min(N, -(-((bt + 1) * 128) // mb) * mb) for bt in range(-(-N // 128)))
+        nt16 = -(-G // 16)
+        cov_tiles = nt16 * (nt16 + 1) // 2 if (mb == 32) else nt16 * nt16
+        cov_flops = 2.0 * B * cov_tiles * 2 * 256 * N
+        line_ms = {k: v[0] / max(v[1], 1) for k, v in lk.items()}
         phi_bytes = 8.0 * F * N
         secondary = {
             "gram_kernel_larger_N": gram_sizes,
@@ -557,12 +587,24 @@ def main():
             "rff_terms_ms": {"F": F, "N": N, "wall_ms_per_call": t_terms * 1e3,
                              "note": "S + S_grad + diag(S_hessian) in one call (reads Phi twice: 2 x 8 F N bytes); the reference: "
                                      "0.02 + 0.11 + 1.0 s"},
-            "line_acq": {"lines": B, "grid": G, "draws": S, "ms": t_line * 1e3, "lines_per_s": B / t_line},
+            "line_acq": {"lines": B, "grid": G, "draws": S, "ms": t_line * 1e3, "lines_per_s": B / t_line,
+                         "entry": "ppbo_line_acq_xi (grid points formed on the device)",
+                         "kernel_ms": {"kstar_kernel": line_ms["line_kstar"], "Y = G K* (dgemm_kernel, 128x128 tiles)": line_ms["line_y"],
+                                       "line_cov_kernel": line_ms["line_cov"], "line_mc_kernel": line_ms["line_mc"]},
+                         "bound": "mfma", "executed_flops": {"Y": y_flops, "covariance data term": cov_flops},
+                         "achieved_TFLOPs_Y": y_flops / (line_ms["line_y"] * 1e-3) / 1e12,
+                         "frac_Y": y_flops / (line_ms["line_y"] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                         "achieved_TFLOPs_cov": cov_flops / (line_ms["line_cov"] * 1e-3) / 1e12,
+                         "frac_cov": cov_flops / (line_ms["line_cov"] * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                         "frac": (y_flops + cov_flops) / (t_line) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                         "note": "frac = all executed MFMA flops of the call over its wall time (kstar, the Monte-Carlo part "
+                                 "and launch gaps included) / fp64 MFMA peak"},
         }
-        try:
-            secondary["per_query_ms"] = per_query_breakdown(torch)
-        except Exception as exc:      # noqa: BLE001  -- a secondary row must never cost the headline line
-            secondary["per_query_ms"] = {"error": repr(exc)}
+        for pq_cfg in ("c2", "c3"):
+            try:
+                secondary[f"per_query_ms_{pq_cfg}"] = per_query_breakdown(torch, pq_cfg)
+            except Exception as exc:      # noqa: BLE001  -- a secondary row must never cost the headline line
+                secondary[f"per_query_ms_{pq_cfg}"] = {"error": repr(exc)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -651,17 +693,20 @@ def main():
                 pass
         # model on the REFERENCE's f_MAP (fixture): parity of the timed path on the fixture's candidates, and
         # BASELINE config 5's "fp32 tolerance check": the same scoring with K* evaluated in fp32 (fp64 accumulation)
-        Sinv_d = eng.pd_inverse(eng.gram(Xd, th, kern))
-        post_ref = eng.posterior(Xd, th, kern, Sinv_d, g["fMAP"], m)
+        need_ref = (not args.no_precision_report) or (world == 1 and not args.no_cpu_baseline and args.config in ("c2", "c3"))
+        if need_ref:
+            Sinv_d = eng.pd_inverse(eng.gram(Xd, th, kern))
+            post_ref = eng.posterior(Xd, th, kern, Sinv_d, g["fMAP"], m)
         sf2 = float(th[2]) ** 2
         rep = {}
-        for nm, f32 in (("fp64", False), ("fp32_kstar", True)):
+        for nm, f32 in (() if args.no_precision_report else (("fp64", False), ("fp32_kstar", True))):
             o = eng.predict(post_ref, g["Xc"], want_best=False, kstar_fp32=f32)
             rep[nm] = {"mu_max_rel_err": float(np.abs(o["mu"].cpu().numpy() - g["mu"]).max() / np.abs(g["mu"]).max()),
                        "var_max_err_over_sf2": float(np.abs(o["var"].cpu().numpy() - g["var"]).max() / sf2)}
-        rep["note"] = ("errors against the reference's own mu / diag Sigma_pred on the fixture's 512 candidates; tolerance 1e-5 "
-                       "applies to fp64 (the product path); the fp32-K* variant is reported, not shipped")
-        line["secondary"]["precision_report"] = rep
+        if rep:
+            rep["note"] = ("errors against the reference's own mu / diag Sigma_pred on the fixture's 512 candidates; tolerance 1e-5 "
+                           "applies to fp64 (the product path); the fp32-K* variant is reported, not shipped")
+            line["secondary"]["precision_report"] = rep
         if world == 1 and not args.no_cpu_baseline and args.config in ("c2", "c3"):   # sigma = 0.001 oracle fits (c4, c5) take minutes to hours
             # the oracle uses the reference's fMAP from the fixture; score the same subsample with that model
             Xs = np.random.default_rng(11).random((256, D))

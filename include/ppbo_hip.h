@@ -260,8 +260,8 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
 /* The same scoring passes for ONE SHARD of a sharded candidate search: nothing comes back to the
  * host and nothing synchronises.  d_record[2] (device) receives (best score, index_offset + its FIRST row index as
  * a double, exact below 2^53) -- (NaN, -1) when no candidate has a non-NaN score -- i.e. exactly the 16-byte record
- * that ppbo_argmax_allgather_record / torch.distributed all-gather.  The score launch reduces its own best (its last
- * workgroup to retire merges the per-block records): kstar, quadform, score are the only launches. */
+ * that ppbo_argmax_allgather_record / torch.distributed all-gather (written by the one-workgroup argmax launch that
+ * ends the pass). */
 int ppbo_predict_record(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
                         int score_kind, double mustar, int64_t index_offset, double* d_record, void* stream);
 

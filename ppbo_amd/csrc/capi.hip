@@ -52,18 +52,6 @@ void* ppbo_pinned(ppbo_ctx* ctx, size_t bytes) {
   return p;
 }
 
-unsigned* ppbo_ticket_counter(ppbo_ctx* ctx) {
-  if (ctx->ticket) return ctx->ticket;
-  void* p = nullptr;
-  if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) {   // synchronous: once per ctx
-    if (p) (void)hipFree(p);
-    ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "ticket counter allocation failed");
-    return nullptr;
-  }
-  ctx->ticket = (unsigned*)p;
-  return ctx->ticket;
-}
-
 int ppbo_host_record(ppbo_ctx* ctx, PpboHostRecord* out) {
   if (!ctx->hostrec) {
     void* h = nullptr;
@@ -148,7 +136,6 @@ int ppbo_ctx_destroy(ppbo_ctx* ctx) {
   for (int i = 0; i < ppbo_ctx::WS_COUNT; ++i)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-  if (ctx->ticket) (void)hipFree(ctx->ticket);
   if (ctx->hostrec) (void)hipHostFree(ctx->hostrec);
   for (int i = 0; i < ppbo_ctx::PF_COUNT; ++i)
     for (auto& pr : ctx->pf_events[i]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -158,7 +145,8 @@ int ppbo_ctx_destroy(ppbo_ctx* ctx) {
 }
 
 static int pf_slot(const char* name) {
-  static const char* names[] = {"gram", "kstar", "quadform", "score", "rff_project", "rff_score", "potrf"};
+  static const char* names[] = {"gram", "kstar", "quadform", "score", "rff_project", "rff_score", "potrf",
+                                "line_kstar", "line_y", "line_cov", "line_mc"};
   for (int i = 0; i < ppbo_ctx::PF_COUNT; ++i)
     if (std::strcmp(name, names[i]) == 0) return i;
   return -1;

@@ -29,7 +29,7 @@ struct ppbo_ctx {
   size_t pinned_bytes = 0;
   // optional per-kernel event timing
   bool profiling = false;
-  enum { PF_GRAM = 0, PF_KSTAR, PF_QUADFORM, PF_SCORE, PF_RFF_PROJECT, PF_RFF_SCORE, PF_POTRF, PF_COUNT };
+  enum { PF_GRAM = 0, PF_KSTAR, PF_QUADFORM, PF_SCORE, PF_RFF_PROJECT, PF_RFF_SCORE, PF_POTRF, PF_LINE_KSTAR, PF_LINE_Y, PF_LINE_COV, PF_LINE_MC, PF_COUNT };
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pf_events[PF_COUNT];
   size_t pf_used[PF_COUNT] = {};
   // kernels whose dynamic-LDS limit has been raised on THIS ctx's device (hipFuncSetAttribute is per device)
@@ -37,7 +37,6 @@ struct ppbo_ctx {
   // tuning knobs, read from the environment once per ctx (ppbo_ctx_create); defaults = measured best
   int qf_variant = 2, qf_order = 258, potrf_gen = 3, rff_nt = 0, gram_variant = -1, rff_score_mfma = 1;
   ppbo_dist_state* dist = nullptr;   // set by ppbo_dist_init
-  unsigned* ticket = nullptr;        // device word, zero between launches: the "last workgroup" ticket of score_kernel
   // host-mapped (pinned, device-visible) result record: [0] value, [1] index as a double, [2] the epoch flag the
   // publishing kernel raises last; the host polls it (ppbo_host_record_wait)
   double* hostrec = nullptr;         // host address
@@ -98,8 +97,6 @@ int ppbo_set_error(ppbo_ctx* ctx, int code, const char* fmt, ...);
 // returns a device pointer of at least `bytes` (contents undefined); nullptr on failure
 void* ppbo_workspace(ppbo_ctx* ctx, int slot, size_t bytes);
 void* ppbo_pinned(ppbo_ctx* ctx, size_t bytes);
-// the ctx's ticket counter (device, 4 bytes used, zeroed once at allocation; whoever draws the last ticket resets it)
-unsigned* ppbo_ticket_counter(ppbo_ctx* ctx);
 // raise a kernel's dynamic-LDS limit to `bytes` once per ctx (i.e. once per device)
 void ppbo_lds_limit(ppbo_ctx* ctx, const void* kernel_fn, int bytes);
 

@@ -16,7 +16,7 @@
 //   Workgroups are ordered candidate-tile-fastest in chunks of 64 tiles (PPBO_QF_ORDER, default 258):
 //   all resident workgroups stream the same G row panel out of L2 while their K* chunk sits in the
 //   Infinity Cache.  PPBO_QF_VARIANT (default 2) selects the measured tile shapes, see DESIGN.md.
-// Pass 3 (score_kernel): slab sums -> var, score, per-block argmax; its last workgroup -> 1 value.
+// Pass 3 (score_kernel): slab sums -> var, score, per-block argmax; (argmax_final_kernel) -> 1 value.
 #include "gemm_f64.h"
 #include "linalg.h"
 #include "score.h"
@@ -723,9 +723,9 @@ int pick_split(int M, int n_q) {
 
 extern "C" {
 
-// the scoring passes of ppbo_predict / ppbo_predict_record: per 65536-candidate chunk kstar -> quadform -> score (the
-// score launch also reduces the chunk's best: its last workgroup merges the per-block records).  Leaves the per-chunk
-// bests in *chunk_best_out (device); with d_record and ONE chunk the score launch writes the record itself.
+// the scoring passes of ppbo_predict / ppbo_predict_record: per 65536-candidate chunk kstar -> quadform -> score ->
+// one-workgroup argmax.  Leaves the per-chunk bests in *chunk_best_out (device); with d_record and ONE chunk the
+// argmax launch writes the record (and raises the publication flag) itself.
 static int predict_passes(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
                           double mustar, double* d_mu, double* d_var, double* d_score, bool want_best,
                           double* d_record, int64_t record_offset, Best** chunk_best_out, int* n_chunks_out,
@@ -761,12 +761,6 @@ static int predict_passes(ppbo_ctx* ctx, const ppbo_model* model, const double* 
   Best* bests = (Best*)ppbo_workspace(ctx, ppbo_ctx::WS_SMALL, (size_t)(sblocks_max + n_chunks) * sizeof(Best));
   if (!bests) return (int)hipErrorOutOfMemory;
   Best* chunk_best = bests + sblocks_max;
-  unsigned* ticket = nullptr;
-  if (want_best) {
-    ticket = ppbo_ticket_counter(ctx);
-    if (!ticket) return (int)hipErrorOutOfMemory;
-  }
-
   for (int64_t ch = 0; ch < n_chunks; ++ch) {
     const int64_t c_beg = ch * chunk_cap;
     const int Mc = (int)((M - c_beg) < chunk_cap ? (M - c_beg) : chunk_cap);
@@ -790,10 +784,13 @@ static int predict_passes(ppbo_ctx* ctx, const ppbo_model* model, const double* 
                                                 model->theta[2] * model->theta[2], score_kind, mustar,
                                                 (long long)c_beg, d_mu ? d_mu + c_beg : nullptr,
                                                 d_var ? d_var + c_beg : nullptr, d_score ? d_score + c_beg : nullptr,
-                                                want_best ? bests : nullptr, ticket, chunk_best + ch,
-                                                one ? d_record : nullptr, (long long)record_offset,
-                                                one ? publish : nullptr, epoch);
+                                                want_best ? bests : nullptr);
     PPBO_LAUNCH_CHECK(ctx);
+    if (want_best) {
+      argmax_final_kernel<<<1, 256, 0, s>>>(bests, sblocks, chunk_best + ch, one ? d_record : nullptr,
+                                            (long long)record_offset, one ? publish : nullptr, epoch);
+      PPBO_LAUNCH_CHECK(ctx);
+    }
   }
   if (d_record && n_chunks > 1) {
     best_record_kernel<<<1, 64, 0, s>>>(chunk_best, (int)n_chunks, (long long)record_offset, d_record, publish, epoch);
@@ -980,7 +977,10 @@ int line_acq_impl(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
                                                                     alpha_per_line, Bc, G, D, gridws);
       xg = gridws;
     }
-    dispatch_kstar(model, xg, M, Kt, ld, part, nullptr, q_per_split, n_split_eff, false, s);
+    {
+      PpboProfScope pf(ctx, ppbo_ctx::PF_LINE_KSTAR, s);
+      dispatch_kstar(model, xg, M, Kt, ld, part, nullptr, q_per_split, n_split_eff, false, s);
+    }
     score_kernel<<<score_blocks(M), SC_THREADS, 0, s>>>(part, n_split_eff, nullptr, nullptr, 0, M, 0.0, PPBO_SCORE_MEAN,
                                                         0.0, 0, mu, nullptr, nullptr, nullptr);
     switch (model->kernel_id) {
@@ -993,10 +993,14 @@ int line_acq_impl(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
     y.A = model->d_G; y.lda = N; y.B = Kt; y.ldb = ld; y.C = Y; y.ldc = ld;
     y.M = N; y.N = M; y.K = N; y.alpha = 1.0; y.beta = 0.0; y.khi_mode = 1; y.tri_block = mblk;
     y.nt_chunk = 64;      // 64 column tiles (8192 points, 134 MB of K*) through all row tiles, heaviest first, then the next 64
-    if (int rc = ppbo_gemm_launch(ctx, y, 0, 0, s)) return rc;
+    {
+      PpboProfScope pf(ctx, ppbo_ctx::PF_LINE_Y, s);
+      if (int rc = ppbo_gemm_launch(ctx, y, 0, 0, s)) return rc;
+    }
     // data term of every line's covariance: K*' Lambda K* + Y'Y, one workgroup per (line, row slice)
     const bool sym = (mblk == 32) && (cov_rows % 32 == 0);
     {
+      PpboProfScope pf(ctx, ppbo_ctx::PF_LINE_COV, s);
       const dim3 cg(Bc, cov_splits);
       const long long pst = (long long)Bc_max * G * G;
       // sym: every chunk of 32 rows is exactly one star: the symmetric form (lower-triangle tiles only)
@@ -1019,8 +1023,11 @@ int line_acq_impl(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
       }
 #undef LC_LAUNCH
     }
-    line_mc_kernel<<<dim3(Bc, nsplit), 256, mc_lds, s>>>(mu, cov, G, d_z, S, mustar, jitter, draws_per_split, mc_part,
-                                                         cov_parts, cov_splits, (long long)Bc_max * G * G, sym ? 1 : 0);
+    {
+      PpboProfScope pf(ctx, ppbo_ctx::PF_LINE_MC, s);
+      line_mc_kernel<<<dim3(Bc, nsplit), 256, mc_lds, s>>>(mu, cov, G, d_z, S, mustar, jitter, draws_per_split, mc_part,
+                                                           cov_parts, cov_splits, (long long)Bc_max * G * G, sym ? 1 : 0);
+    }
     mc_finish_kernel<<<(Bc + 255) / 256, 256, 0, s>>>(mc_part, Bc, nsplit, S, d_ei ? d_ei + b0 : nullptr,
                                                       d_varmax ? d_varmax + b0 : nullptr);
     PPBO_LAUNCH_CHECK(ctx);

@@ -36,129 +36,96 @@ __device__ __forceinline__ Best block_best(Best b, Best* sh) {
   return b;  // valid in thread 0
 }
 
-// Geometry of the score pass: a workgroup finishes SC_CAND candidates at a time; its SC_WAVES wavefronts split the partial
-// slabs of those candidates between them (wavefront w sums slabs w, w + SC_WAVES, ...: every load of the pass is in flight at
+// Geometry of the score pass: a workgroup finishes SC_CAND candidates; its SC_WAVES wavefronts split the partial slabs
+// of those candidates between them (wavefront w sums slabs w, w + SC_WAVES, ...: every load of the pass is in flight at
 // once -- the first version had one thread walk all 2 n_mu + n_slab slabs of its candidate, a dependent chain of up
 // to 144 strided loads: 38 us for 8192 candidates, 27 us for 65536, on a pass that moves 9-25 MB), the wavefront
 // sums meet in LDS and are added in wavefront order (a fixed order: results do not depend on timing).
+// The launch-wide best is a SECOND, one-workgroup launch (argmax_final_kernel).  Round 4 tried to fold it into this
+// kernel ("the last workgroup to retire merges the records": a device-scope ticket per workgroup): the tickets cost
+// ~40 ns per workgroup whatever their layout -- one word, or 32 group words + a top word -- because every one of
+// them is a release at device scope: 45-51 us for the 1024 workgroups of a 65536-candidate launch against 6 + 3 us
+// for the two launches.
 constexpr int SC_CAND = 64, SC_WAVES = 16, SC_THREADS = SC_CAND * SC_WAVES;
-// at most SC_MAX_BLOCKS workgroups (each walks its tiles): the "last workgroup" ticket is one device-scope atomic per
-// workgroup on ONE address, and those serialise across the eight XCDs (~40 ns each: 1024 of them cost more than the pass)
-constexpr int SC_MAX_BLOCKS = 256;
-static inline int score_blocks(long long M) {
-  const long long t = (M + SC_CAND - 1) / SC_CAND;
-  return (int)(t < SC_MAX_BLOCKS ? t : SC_MAX_BLOCKS);
-}
+static inline int score_blocks(long long M) { return (int)((M + SC_CAND - 1) / SC_CAND); }
 
-// Scores + per-block best + (when `counter` is given) the launch-wide best in the SAME launch: the last workgroup to
-// retire -- the one whose ticket from `counter` is gridDim.x - 1 -- merges the per-block records and writes
-// *final_out; with `record` it also writes the 16-byte (value, GLOBAL index as a double: exact below 2^53) record
-// that the sharded search all-gathers (index + record_offset; an empty / all-NaN launch: (NaN, -1)) and, with
-// `publish`, raises publish[0] to `epoch` AFTER the record with system-scope release semantics (the record may live
-// in host-mapped memory: the host polls the flag instead of waiting for a copy and a stream synchronisation).  The
-// merge is a max under a total order (value, then lower index), so the result does not depend on which workgroup
-// comes last.  The ticket counter is zero whenever no launch is in flight: the last workgroup resets it.
 __global__ __launch_bounds__(SC_THREADS) void score_kernel(const double* __restrict__ mu_part, int n_mu,
                                                            const double* __restrict__ t_part,
                                                            const double* __restrict__ slab, int n_slab, int M,
                                                            double sf2, int kind, double mustar, long long idx_base,
                                                            double* __restrict__ mu_out, double* __restrict__ var_out,
-                                                           double* __restrict__ score_out, Best* __restrict__ blk_best,
-                                                           unsigned* __restrict__ counter = nullptr,
-                                                           Best* __restrict__ final_out = nullptr,
-                                                           double* __restrict__ record = nullptr,
+                                                           double* __restrict__ score_out, Best* __restrict__ blk_best) {
+  __shared__ double part[3][SC_WAVES][SC_CAND];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * SC_CAND + lane;
+  double pm = 0.0, pt = 0.0, pq = 0.0;
+  if (c < M) {
+    for (int s = wave; s < n_mu; s += SC_WAVES) pm += mu_part[(size_t)s * M + c];
+    if (slab) {
+      for (int s = wave; s < n_mu; s += SC_WAVES) pt += t_part[(size_t)s * M + c];
+      for (int s = wave; s < n_slab; s += SC_WAVES) pq += slab[(size_t)s * M + c];
+    }
+  }
+  part[0][wave][lane] = pm;
+  part[1][wave][lane] = pt;
+  part[2][wave][lane] = pq;
+  __syncthreads();
+  if (wave != 0) return;                 // the rest is one wavefront's work
+  Best b{0.0, -1};
+  if (c < M) {
+    double mu = 0.0, t = 0.0, q = 0.0;
+#pragma unroll
+    for (int w = 0; w < SC_WAVES; ++w) { mu += part[0][w][lane]; t += part[1][w][lane]; q += part[2][w][lane]; }
+    const double var = slab ? sf2 + t + q : sf2;
+    double sc;
+    if (kind == PPBO_SCORE_MEAN) sc = mu;
+    else if (kind == PPBO_SCORE_VARIANCE) sc = var;
+    else {
+      const double d = mu - mustar;
+      const double sd = sqrt(fmax(var, 0.0));
+      if (sd > 0.0) {
+        const double z = d / sd;
+        sc = d * norm_cdf(z) + sd * 0.39894228040143267794 * exp(-0.5 * z * z);
+      } else sc = fmax(d, 0.0);
+    }
+    if (mu_out) mu_out[c] = mu;
+    if (var_out) var_out[c] = var;
+    if (score_out) score_out[c] = sc;
+    if (sc == sc) { b.val = sc; b.idx = idx_base + c; }
+  }
+  if (!blk_best) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Best other;
+    other.val = __shfl_xor(b.val, o, 64);
+    other.idx = __shfl_xor(b.idx, o, 64);
+    b = best_merge(b, other);
+  }
+  if (lane == 0) blk_best[blockIdx.x] = b;
+}
+
+// per-block records of one launch -> *out; with `record` also the 16-byte (value, GLOBAL index as a double: exact
+// below 2^53; index + record_offset; (NaN, -1) when nothing scored) record that the sharded search all-gathers, and
+// with `publish` the flag publish[0] raised to `epoch` AFTER the record with system-scope release semantics (the
+// record may live in host-mapped memory: the host polls the flag instead of waiting for a copy and a stream
+// synchronisation)
+__global__ __launch_bounds__(256) void argmax_final_kernel(const Best* __restrict__ blk_best, int n,
+                                                           Best* __restrict__ out, double* __restrict__ record = nullptr,
                                                            long long record_offset = 0,
                                                            unsigned long long* __restrict__ publish = nullptr,
                                                            unsigned long long epoch = 0) {
-  __shared__ double part[3][SC_WAVES][SC_CAND];
-  __shared__ Best sh[SC_WAVES];
-  __shared__ unsigned s_ticket;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ntiles = (M + SC_CAND - 1) / SC_CAND;
-  Best b{0.0, -1};                       // wavefront 0: this lane's best over the tiles of the workgroup
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int c = tile * SC_CAND + lane;
-    double pm = 0.0, pt = 0.0, pq = 0.0;
-    if (c < M) {
-      for (int s = wave; s < n_mu; s += SC_WAVES) pm += mu_part[(size_t)s * M + c];
-      if (slab) {
-        for (int s = wave; s < n_mu; s += SC_WAVES) pt += t_part[(size_t)s * M + c];
-        for (int s = wave; s < n_slab; s += SC_WAVES) pq += slab[(size_t)s * M + c];
-      }
-    }
-    part[0][wave][lane] = pm;
-    part[1][wave][lane] = pt;
-    part[2][wave][lane] = pq;
-    __syncthreads();
-    if (wave == 0 && c < M) {
-      double mu = 0.0, t = 0.0, q = 0.0;
-#pragma unroll
-      for (int w = 0; w < SC_WAVES; ++w) { mu += part[0][w][lane]; t += part[1][w][lane]; q += part[2][w][lane]; }
-      const double var = slab ? sf2 + t + q : sf2;
-      double sc;
-      if (kind == PPBO_SCORE_MEAN) sc = mu;
-      else if (kind == PPBO_SCORE_VARIANCE) sc = var;
-      else {
-        const double d = mu - mustar;
-        const double sd = sqrt(fmax(var, 0.0));
-        if (sd > 0.0) {
-          const double z = d / sd;
-          sc = d * norm_cdf(z) + sd * 0.39894228040143267794 * exp(-0.5 * z * z);
-        } else sc = fmax(d, 0.0);
-      }
-      if (mu_out) mu_out[c] = mu;
-      if (var_out) var_out[c] = var;
-      if (score_out) score_out[c] = sc;
-      if (sc == sc) b = best_merge(b, Best{sc, idx_base + c});
-    }
-    __syncthreads();                     // `part` is rewritten by the next tile
-  }
-  if (!blk_best) return;
-  if (wave == 0) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      Best other;
-      other.val = __shfl_xor(b.val, o, 64);
-      other.idx = __shfl_xor(b.idx, o, 64);
-      b = best_merge(b, other);
-    }
-    if (lane == 0) {
-      // the record goes out with device-scope atomics (it must be visible to a workgroup on another XCD, whose L2 is
-      // not ours), then the ticket is drawn with release / acquire semantics
-      __hip_atomic_store(&blk_best[blockIdx.x].val, b.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&blk_best[blockIdx.x].idx, b.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (counter) s_ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  if (!blk_best || !counter) return;
-  __syncthreads();
-  if (s_ticket != gridDim.x - 1) return;
-  Best f{0.0, -1};
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) {
-    Best o;
-    o.val = __hip_atomic_load(&blk_best[i].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    o.idx = __hip_atomic_load(&blk_best[i].idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    f = best_merge(f, o);
-  }
-  f = block_best(f, sh);
-  if (threadIdx.x == 0) {
-    if (final_out) *final_out = f;
-    if (record) {
-      record[0] = f.idx < 0 ? NAN : f.val;
-      record[1] = f.idx < 0 ? -1.0 : (double)(f.idx + record_offset);
-    }
-    __hip_atomic_store(counter, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    if (publish) __hip_atomic_store(publish, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
-__global__ __launch_bounds__(256) void argmax_final_kernel(const Best* __restrict__ blk_best, int n,
-                                                           Best* __restrict__ out) {
   __shared__ Best sh[4];
   Best b{0.0, -1};
   for (int i = threadIdx.x; i < n; i += blockDim.x) b = best_merge(b, blk_best[i]);
   b = block_best(b, sh);
-  if (threadIdx.x == 0) *out = b;
+  if (threadIdx.x == 0) {
+    if (out) *out = b;
+    if (record) {
+      record[0] = b.idx < 0 ? NAN : b.val;
+      record[1] = b.idx < 0 ? -1.0 : (double)(b.idx + record_offset);
+    }
+    if (publish) __hip_atomic_store(publish, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // per-chunk bests -> the 16-byte (value, global index as a double) record of a sharded search; one wavefront

@@ -1,0 +1,15 @@
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r4n
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+python tools/predict_scaling.py > $OUT/scaling.txt 2> $OUT/scaling.err
+python tools/fit_only.py c3 > $OUT/fit_wall.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-secondary --no-precision-report > $OUT/stats_bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/fitprof -- python3 $GRAFT_REPO_ROOT/tools/fit_only.py c3 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/dev/trace_summary.py $OUT/fitprof 260 > $OUT/fit_trace.txt
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+rm -rf $OUT/fitprof $OUT/stats
+bash tools/pmc_quadform.sh > $OUT/pmc.log 2>&1
+python tools/pmc_summary.py gpurun_out/pmc > $OUT/pmc_hot_kernels.json
+rm -rf gpurun_out/pmc
