@@ -35,7 +35,7 @@ struct ppbo_ctx {
   // kernels whose dynamic-LDS limit has been raised on THIS ctx's device (hipFuncSetAttribute is per device)
   std::vector<const void*> lds_raised;
   // tuning knobs, read from the environment once per ctx (ppbo_ctx_create); defaults = measured best
-  int qf_variant = 2, qf_order = 258, potrf_gen = 3, rff_nt = 0, gram_variant = -1, rff_score_mfma = 1;
+  int qf_variant = 2, qf_order = 514, potrf_gen = 3, rff_nt = 0, gram_variant = -1, rff_score_mfma = 1;
   ppbo_dist_state* dist = nullptr;   // set by ppbo_dist_init
   // host-mapped (pinned, device-visible) result record: [0] value, [1] index as a double, [2] the epoch flag the
   // publishing kernel raises last; the host polls it (ppbo_host_record_wait)

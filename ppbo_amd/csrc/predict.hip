@@ -13,7 +13,7 @@
 //   in registers.
 // Pass 2 (quadform_kernel, fp64 MFMA): Y = G K* on 128x128 tiles (8 wavefronts of 32x64), K range cut
 //   at the block-triangular edge per wavefront, epilogue = column sums of Y^2 into per-row-tile slabs.
-//   Workgroups are ordered candidate-tile-fastest in chunks of 64 tiles (PPBO_QF_ORDER, default 258):
+//   Workgroups are ordered candidate-tile-fastest in chunks of 128 tiles (PPBO_QF_ORDER, default 514):
 //   all resident workgroups stream the same G row panel out of L2 while their K* chunk sits in the
 //   Infinity Cache.  PPBO_QF_VARIANT (default 2) selects the measured tile shapes, see DESIGN.md.
 // Pass 3 (score_kernel): slab sums -> var, score, per-block argmax; (argmax_final_kernel) -> 1 value.
@@ -261,7 +261,7 @@ int launch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, int
   ppbo_lds_limit(ctx, (const void*)quadform_kernel<C, MINW, false>, (int)lds);
   const int ntm = (N + C::BM - 1) / C::BM, ntn = (Mc + C::BN - 1) / C::BN;
   const int grid = ntm * ntn;
-  const int order = ctx->qf_order;   // PPBO_QF_ORDER; default 258 = candidate-tile fastest in chunks of 64 tiles (measured best)
+  const int order = ctx->qf_order;   // PPBO_QF_ORDER; default 514 = candidate-tile fastest in chunks of 128 tiles (measured best: profiles/r04_quadform_traffic_vs_order.txt)
   const int swz = ((grid % 8 == 0 && grid >= 64) ? (order & 1) : 0) | (order & ~1);
   // every tile in bounds, 16-byte aligned, and every K range a multiple of 16?
   const bool fast = (N % C::BM == 0) && (Mc % C::BN == 0) && (N % 2 == 0) && (ldk % 2 == 0) && (mblk % 16 == 0 || mblk == 1 || (C::BM % mblk == 0)) &&
