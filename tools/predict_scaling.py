@@ -95,8 +95,8 @@ t_torch = legs("c3", 65536, "torch")
 print("\n# fixed cost of the collective at world = 1, per step (difference of the measured legs, ms):")
 for G in (1, 2, 4, 8):
     print(f"#   M/rank {65536 // G:6d}: no collective {t_none[G]:.3f} | library communicator (ppbo_search_sharded) {t_capi[G]:.3f} "
-          f"(+{(t_capi[G] - t_none[G]) * 1e3:.1f} us) | torch.distributed nccl + ppbo_argmax_combine {t_torch[G]:.3f} "
-          f"(+{(t_torch[G] - t_none[G]) * 1e3:.1f} us)")
+          f"({(t_capi[G] - t_none[G]) * 1e3:+.1f} us) | torch.distributed nccl + ppbo_argmax_combine {t_torch[G]:.3f} "
+          f"({(t_torch[G] - t_none[G]) * 1e3:+.1f} us)")
 table("C3 (N=2048, D=20), torch.distributed nccl binding [bench.py's default]", 65536, t_torch,
       "G = 1 row of bench.py itself runs without a collective")
 table("C3 (N=2048, D=20), library communicator binding [bench.py --collective capi]", 65536, t_capi, "")
