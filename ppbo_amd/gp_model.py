@@ -704,9 +704,17 @@ class GPModel:
             return np.asarray(x0, dtype=float).reshape(D,), self.mu_pred(x0), np.asarray(x0, dtype=float).reshape(1, D)
         found.sort(key=lambda p: -p[0])
         xstar = found[0][1].copy()
-        local = [found[0][1]]
-        for _, x in found[1:]:                                          # distinct maxima > 0.1 apart (gp_model.py:430)
-            if all(np.linalg.norm(x - y) > 1e-1 for y in local):
-                local.append(x)
-        xstars_local = np.vstack(local).reshape(-1, D)
+        # distinct maxima > 0.1 apart, best first (gp_model.py:430-431): one distance matrix, then a greedy sweep that
+        # strikes everything within 0.1 of a kept maximum (the pairwise Python loop this replaces cost 10 ms at D = 20,
+        # where 3 trials return ~90 converged points and ~45 distinct maxima: more than the searches themselves)
+        P = np.stack([x for _, x in found])
+        sq = (P * P).sum(axis=1)
+        d2 = np.maximum(sq[:, None] + sq[None, :] - 2.0 * (P @ P.T), 0.0)
+        struck = np.zeros(len(P), dtype=bool)
+        keep = []
+        for i in range(len(P)):
+            if not struck[i]:
+                keep.append(i)
+                struck |= d2[i] <= 1e-2
+        xstars_local = P[keep].reshape(-1, D)
         return xstar.reshape(D,), self.mu_pred(xstar), xstars_local
