@@ -245,6 +245,11 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
                  f"(or run `python bench.py --gpus {args.gpus}` without torchrun and let it spawn the ranks)")
+    if world > 1:
+        # the side measurements (RFF, line acquisitions, per-query breakdown, precision report, cpu_baseline) belong to
+        # the N = 1 line: with several ranks they would keep rank 0 busy for half a minute while the others wait in
+        # destroy_process_group
+        args.no_secondary = args.no_precision_report = args.no_cpu_baseline = True
     wl_name, m_default, scaling_default = WORKLOADS[args.config]
     scaling = args.scaling or scaling_default
     M_arg = args.candidates or m_default
