@@ -709,7 +709,9 @@ __global__ __launch_bounds__(LB_T) void lbfgs_step_kernel(WhState* __restrict__ 
 __global__ __launch_bounds__(256) void beta_lt_kernel(const int* __restrict__ status, const double* __restrict__ ft,
                                                       int N, int mblk, int n_q, double sigma,
                                                       const double* __restrict__ U, double* __restrict__ beta,
-                                                      double* __restrict__ tq, double* __restrict__ u) {
+                                                      double* __restrict__ tq, double* __restrict__ u,
+                                                      const int* __restrict__ need_gf,
+                                                      const double* __restrict__ Sinv, double* __restrict__ v) {
   extern __shared__ __attribute__((aligned(16))) double blds[];     // f [N] | beta [N]
   if (*status != 0) return;
   double* sf = blds;
@@ -754,6 +756,23 @@ __global__ __launch_bounds__(256) void beta_lt_kernel(const int* __restrict__ st
   }
   const double su = wave_sum_dpp((a0 + a1) + (a2 + a3));
   if (lane == 0) u[i] = su;
+  if (*need_gf == 0) return;
+  // v_i = (Sigma^-1 f)_i for the |grad_f| rule, wanted only near the end: f is in LDS already, and a launch of its
+  // own costs its 4-5 us in EVERY slot, gated off or not
+  const double* sr = Sinv + (size_t)i * N;
+  a0 = a1 = a2 = a3 = 0.0;
+  k = 2 * lane;
+  for (; k + 128 < N; k += 256) {
+    const double2 u0 = *reinterpret_cast<const double2*>(sr + k), b0 = *reinterpret_cast<const double2*>(sf + k);
+    const double2 u1 = *reinterpret_cast<const double2*>(sr + k + 128), b1 = *reinterpret_cast<const double2*>(sf + k + 128);
+    a0 += u0.x * b0.x; a1 += u0.y * b0.y; a2 += u1.x * b1.x; a3 += u1.y * b1.y;
+  }
+  for (; k < N; k += 128) {
+    const double2 u0 = *reinterpret_cast<const double2*>(sr + k), b0 = *reinterpret_cast<const double2*>(sf + k);
+    a0 += u0.x * b0.x; a1 += u0.y * b0.y;
+  }
+  const double sv = wave_sum_dpp((a0 + a1) + (a2 + a3));
+  if (lane == 0) v[i] = sv;
 }
 
 // U = L^T (upper triangle, zero below; row pitch N); 32 x 32 tiles through LDS
@@ -1215,19 +1234,25 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
     if (blds > 48 * 1024) ppbo_lds_limit(ctx, (const void*)beta_lt_kernel, 144 * 1024);
   }
   auto enqueue_slot = [&]() -> int {
+    bool v_done = false;                // v = Sigma^-1 f rode along with the u launch
     if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, zt, ft, 0, 1, s, run)) return rc;                  // f = L zt
     if (fused) {
-      beta_lt_kernel<<<(N + 3) / 4, 256, blds, s>>>(&st->status, ft, N, mblk, n_q, sigma, U, beta, tq, u);
+      beta_lt_kernel<<<(N + 3) / 4, 256, blds, s>>>(&st->status, ft, N, mblk, n_q, sigma, U, beta, tq, u, &st->need_gf,
+                                                    d_Sigma_inv, v);
+      v_done = true;
     } else {
       // u = L^T beta(f): beta rebuilt inside the product's first pass where the star size allows (m = 31: yes)
-      const int rcb = ppbo_gemvT_beta_async(ctx, d_L, N, ldl, ft, mblk, sigma, u, beta, tq, s, run);
+      const int rcb = ppbo_gemvT_beta_async(ctx, d_L, N, ldl, ft, mblk, sigma, u, beta, tq, s, run, d_Sigma_inv, N, v,
+                                            run_gf);
       if (rcb > 1) return rcb;
+      v_done = rcb == 0;
       if (rcb == 1) {
         laplace_kernel<<<(n_q + 3) / 4, 256, 0, s>>>(ft, N, mblk, n_q, sigma, tq, beta, nullptr, nullptr);
         if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, beta, u, 1, 1, s, run)) return rc;             // u = L^T beta
       }
     }
-    if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, ft, v, 0, 0, s, run_gf)) return rc;          // v = Sigma^-1 f
+    if (!v_done)
+      if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, ft, v, 0, 0, s, run_gf)) return rc;        // v = Sigma^-1 f
     lbfgs_step_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, v, beta, tq, basis, dbg, prog);
     return 0;
   };

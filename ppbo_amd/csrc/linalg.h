@@ -59,8 +59,12 @@ struct PpboGate {
 int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const double* d_x, double* d_y, int trans,
                     int lower, hipStream_t s, PpboGate gate = PpboGate());
 // u = L^T beta(f) in two launches with beta[N] and tq[N / mblk] as by-products (one launch less than laplace_kernel +
-// ppbo_gemv_async); returns 1 without enqueueing anything when mblk is not a multiple of 16 or exceeds 64
+// ppbo_gemv_async); returns 1 without enqueueing anything when mblk is not a multiple of 16 or exceeds 64.
+// With d_R: the first launch also carries rv = R f (full N x N, by rows) behind its own gate -- a second product with
+// the same f that would otherwise be a launch of its own
 int ppbo_gemvT_beta_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, const double* d_f, int mblk, double sigma,
-                          double* d_u, double* d_beta, double* d_tq, hipStream_t s, PpboGate gate = PpboGate());
+                          double* d_u, double* d_beta, double* d_tq, hipStream_t s, PpboGate gate = PpboGate(),
+                          const double* d_R = nullptr, int ldr = 0, double* d_rv = nullptr,
+                          PpboGate rider_gate = PpboGate());
 // out[0] = sum_i x_i y_i  (deterministic single-block reduction)
 int ppbo_dot_async(ppbo_ctx* ctx, const double* d_x, const double* d_y, int N, double* d_out, hipStream_t s);

@@ -718,13 +718,10 @@ __global__ __launch_bounds__(256) void trtri_diag_kernel(const double* __restric
   }
 }
 
-// y = T x, one wavefront per row
-__global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ T, int rows, int cols, int ldt,
-                                                        const double* __restrict__ x, const double* __restrict__ y0,
-                                                        double* __restrict__ y, int lower, PpboGate gate) {
-  if (gate.closed()) return;
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+// row i of y = T x by one wavefront (all 64 lanes call it)
+__device__ __forceinline__ void gemv_row(const double* __restrict__ T, int rows, int cols, int ldt,
+                                         const double* __restrict__ x, const double* __restrict__ y0,
+                                         double* __restrict__ y, int lower, int i, int lane) {
   if (i >= rows) return;
   const int kend = (lower && i + 1 < cols) ? (i + 1) : cols;
   const double* row = T + (size_t)i * ldt;
@@ -759,6 +756,14 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
   }
   s = wave_sum(s);
   if (lane == 0) y[i] = y0 ? y0[i] - s : s;
+}
+
+// y = T x, one wavefront per row
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ T, int rows, int cols, int ldt,
+                                                        const double* __restrict__ x, const double* __restrict__ y0,
+                                                        double* __restrict__ y, int lower, PpboGate gate) {
+  if (gate.closed()) return;
+  gemv_row(T, rows, cols, ldt, x, y0, y, lower, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // y = T^T x in two deterministic passes.  partial[split][j] = sum_{i in split, i >= (lower ? j : 0)} T[i][j] x[i]
@@ -798,8 +803,17 @@ __global__ __launch_bounds__(256) void gemvT_beta_partial_kernel(const double* _
                                                                  const double* __restrict__ f, int mblk, double sigma,
                                                                  double* __restrict__ partial,
                                                                  double* __restrict__ beta_out, double* __restrict__ tq,
-                                                                 PpboGate gate) {
+                                                                 PpboGate gate, int n_split, const double* __restrict__ R,
+                                                                 int ldr, double* __restrict__ rv, PpboGate rider_gate) {
   if (gate.closed()) return;
+  if ((int)blockIdx.y >= n_split) {
+    // the rider: rv = R f by rows (the search's v = Sigma^-1 f, wanted only near the end: a launch of its own costs
+    // its 4-5 us in EVERY slot, gated off or not)
+    if (rider_gate.closed()) return;
+    gemv_row(R, N, N, ldr, f, nullptr, rv, 0, (((int)blockIdx.y - n_split) * (int)gridDim.x + (int)blockIdx.x) * 4 + (threadIdx.x >> 6),
+             threadIdx.x & 63);
+    return;
+  }
   __shared__ double sb[GT_ROWS];
   const int i0 = blockIdx.y * GT_ROWS;
   if (i0 + GT_ROWS <= (int)blockIdx.x * 256) return;      // no row of this split reaches these columns
@@ -1059,13 +1073,16 @@ int ppbo_gemv_rect_async(ppbo_ctx* ctx, const double* d_T, int rows, int cols, i
 // u = L^T beta(f) with beta and the per-query likelihood sums as by-products (see gemvT_beta_partial_kernel); returns 1
 // (nothing enqueued) when the star size does not allow it: the caller then runs laplace_kernel + ppbo_gemv_async
 int ppbo_gemvT_beta_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, const double* d_f, int mblk, double sigma,
-                          double* d_u, double* d_beta, double* d_tq, hipStream_t s, PpboGate gate) {
+                          double* d_u, double* d_beta, double* d_tq, hipStream_t s, PpboGate gate, const double* d_R,
+                          int ldr, double* d_rv, PpboGate rider_gate) {
   if (mblk % GT_ROWS != 0 || mblk > 64 || N % mblk != 0) return 1;
   const int n_split = (N + GT_ROWS - 1) / GT_ROWS;
   double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, (size_t)n_split * N * sizeof(double));
   if (!part) return (int)hipErrorOutOfMemory;
-  gemvT_beta_partial_kernel<<<dim3((N + 255) / 256, n_split), 256, 0, s>>>(d_L, N, ldl, d_f, mblk, sigma, part, d_beta,
-                                                                           d_tq, gate);
+  const int gx = (N + 255) / 256;
+  const int rider_y = d_R ? ((N + 3) / 4 + gx - 1) / gx : 0;      // extra workgroup rows: four rows of R per workgroup
+  gemvT_beta_partial_kernel<<<dim3(gx, n_split + rider_y), 256, 0, s>>>(d_L, N, ldl, d_f, mblk, sigma, part, d_beta,
+                                                                        d_tq, gate, n_split, d_R, ldr, d_rv, rider_gate);
   sum_slabs_kernel<<<(N + 15) / 16, 256, 0, s>>>(part, n_split, N, nullptr, d_u, 1, gate);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
