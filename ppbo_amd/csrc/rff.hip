@@ -9,6 +9,7 @@
 //                features split across blockIdx.y into partial slabs; Phi(Xc) never exists.
 //   rff_terms  : f = Phi^T omega (split GEMV), per-query likelihood weights (one wavefront per
 //                query), then one wavefront per feature row for S_grad / diag(S_hessian).
+#include <chrono>
 #include "linalg.h"
 #include "rffmath.h"
 #include "score.h"
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(256) void phiT_omega_kernel(const double* __restric
   int f1 = f0 + f_per_split;
   if (f1 > F) f1 = F;
   double s = 0.0;
+#pragma unroll 8
   for (int f = f0; f < f1; ++f) s += Phi[(size_t)f * N + n] * omega[f];
   partial[(size_t)blockIdx.y * N + n] = s;
 }
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const double* __restrict
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= N) return;
   double s = 0.0;
+#pragma unroll 8
   for (int k = 0; k < n_split; ++k) s += partial[(size_t)k * N + j];
   y[j] = s;
 }
@@ -357,65 +360,266 @@ __global__ __launch_bounds__(1024) void rff_S_kernel(const double* __restrict__ 
   }
 }
 
-// One trust-region step of update_omega_MAP (random_fourier_sampler.py:124-132).  The Hessian of S is diagonal, so the
-// subproblem trust-exact solves -- min -g.s + 1/2 s.(C s), |s| <= radius, C = diag(max(-h, 1e-12)) -- has the closed
-// form s_i = g_i / (c_i + lam): lam = 0 when the Newton step fits, otherwise the root of |s(lam)| = radius, found by
-// the More-Sorensen Newton iteration on 1/|s| - 1/radius (monotone from lam = 0 since every c_i + lam > 0).
-// trial = omega + s;  out[0] = |Newton step| (>= radius <=> the step is on the boundary), out[1] = predicted gain
-// g.s - 1/2 s.(C s), out[2] = |g|.
-__global__ __launch_bounds__(1024) void rff_newton_step_kernel(const double* __restrict__ omega, const double* __restrict__ g,
-                                                               const double* __restrict__ h, int F, double radius,
-                                                               double* __restrict__ trial, double* __restrict__ out) {
+// ---- update_omega_MAP as a device-resident loop ---------------------------------------------------------------
+// The trust region's state lives on the device and one 1024-thread workgroup takes its decisions (om_step_kernel), so
+// an iteration is FOUR launches and no read-back: f-partials at the trial point, weights (summing the partials on the
+// way), the row pass (gradient, Hessian diagonal), and the step kernel, which first judges the trial it finds
+// evaluated (S, |gradient|, rho, radius, acceptance) and then forms the next one.  The host enqueues slots a few
+// ahead of the device and watches a host-mapped progress word, exactly as the whitened f_MAP search does (fit.hip).
+// Before: 9 enqueues and a stream synchronisation per iteration (381 of them at C2).
+struct OmHead {
+  int status;        // 0 running | 1 |gradient| < gtol | 2 maxiter | 3 radius < 1e-14
+  int it;            // steps taken
+  int cur;           // which of the two (omega, gradient, Hessian diagonal) sets is the accepted point
+  int pending;       // 0 nothing to judge | 1 a trial step | 2 the start point (accepted as it is)
+  int maxiter, pad_;
+  double S, radius, gn, nrm, pred, gtol;
+};
+struct OmProgress {
+  unsigned long long* word;   // device view of the host-mapped progress word: status << 32 | it
+  int* head;                  // device view of the host-mapped copy of OmHead (written when status != 0)
+};
+
+__global__ void om_init_kernel(OmHead* st, int maxiter, double gtol) {
+  st->status = 0; st->it = 0; st->cur = 1; st->pending = 2; st->maxiter = maxiter; st->pad_ = 0;
+  st->S = 0.0; st->radius = 1.0; st->gn = INFINITY; st->nrm = 0.0; st->pred = 0.0; st->gtol = gtol;
+}
+
+// partial[split][n] = sum_{f in split} Phi[f][n] omega_trial[f]
+__global__ __launch_bounds__(256) void om_phiT_kernel(const OmHead* __restrict__ st, const double* __restrict__ Phi,
+                                                      int F, int N, const double* __restrict__ buf, int f_per_split,
+                                                      double* __restrict__ partial) {
+  if (st->status != 0) return;
+  const double* omega = buf + (size_t)(1 - st->cur) * 3 * F;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int f0 = blockIdx.y * f_per_split;
+  int f1 = f0 + f_per_split;
+  if (f1 > F) f1 = F;
+  double s = 0.0;
+#pragma unroll 8
+  for (int f = f0; f < f1; ++f) s += Phi[(size_t)f * N + n] * omega[f];      // eight loads in flight per lane
+  partial[(size_t)blockIdx.y * N + n] = s;
+}
+
+// rff_weights_kernel with f summed from the partials on the way (same order as sum_parts_kernel)
+template <int NS>
+__global__ __launch_bounds__(256) void om_weights_kernel(const OmHead* __restrict__ st, const double* __restrict__ partial,
+                                                         int N, int mblk, int n_q, double sigma,
+                                                         double* __restrict__ tq, double* __restrict__ a,
+                                                         double* __restrict__ h) {
+  if (st->status != 0) return;
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n_q) return;
+  const int m = mblk - 1, i = q * mblk;
+  auto fsum = [&](int j) {               // all NS loads in flight (a runtime trip count made them a dependent chain)
+    double v[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) v[k] = partial[(size_t)k * N + j];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s += v[k];
+    return s;
+  };
+  const double f0 = fsum(i);
+  double sphi = 0.0;
+  for (int r = 1 + lane; r <= m; r += 64) {
+    const int j = i + r;
+    const double delta = (fsum(j) - f0) / sigma;
+    sphi += 0.5 * erfc(-0.5 * delta);
+    const double p2 = INV_SQRT_4PI * exp(-0.25 * (delta * delta));
+    a[j] = p2 / (sigma * (double)m);
+    h[j] = -0.5 * delta * p2 / ((double)m * sigma * sigma);
+  }
+  sphi = wave_sum(sphi);
+  if (lane == 0) { tq[q] = sphi; a[i] = 0.0; h[i] = 0.0; }
+}
+
+// rff_rows_kernel on the trial set
+__global__ __launch_bounds__(256) void om_rows_kernel(const OmHead* __restrict__ st, const double* __restrict__ Phi,
+                                                      int F, int N, int mblk, double* __restrict__ buf,
+                                                      const double* __restrict__ a, const double* __restrict__ h) {
+  if (st->status != 0) return;
+  double* set = buf + (size_t)(1 - st->cur) * 3 * F;
+  const int lane = threadIdx.x & 63;
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= F) return;
+  const double* row = Phi + (size_t)f * N;
+  double sg = 0.0, sh = 0.0;
+  for (int n = lane; n < N; n += 64) {
+    const int o = (n / mblk) * mblk;
+    const double dphi = row[n] - row[o];
+    sg += dphi * a[n];
+    sh += dphi * dphi * h[n];
+  }
+  sg = wave_sum(sg);
+  sh = wave_sum(sh);
+  if (lane == 0) {
+    set[F + f] = -set[f] - sg;
+    set[2 * F + f] = -1.0 - sh;
+  }
+}
+
+// Judge the evaluated trial, then form the next one: one trust-region step of update_omega_MAP
+// (random_fourier_sampler.py:124-132; acceptance and radius rules are SciPy trust-exact's).  The Hessian of S is
+// diagonal, so the subproblem trust-exact solves -- min -g.s + 1/2 s.(C s), |s| <= radius, C = diag(max(-h, 1e-12)) --
+// has the closed form s_i = g_i / (c_i + lam): lam = 0 when the Newton step fits, otherwise the root of
+// |s(lam)| = radius, found by the More-Sorensen Newton iteration on 1/|s| - 1/radius (monotone from lam = 0 since
+// every c_i + lam > 0).  trial = omega + s; nrm = |Newton step| (>= radius <=> the step is on the boundary),
+// pred = g.s - 1/2 s.(C s), gn = |g| at the accepted point (what h_gradnorm reports).
+template <int PER>
+__global__ __launch_bounds__(1024) void om_step_kernel(OmHead* __restrict__ st, double* __restrict__ buf, int F,
+                                                       const double* __restrict__ tq, int n_q, int m,
+                                                       double* __restrict__ omega_out, OmProgress prog) {
+  // PER > 0: F <= 1024 PER and both sets sit in registers after ONE round of loads (every later pass over the
+  // vectors -- |gradient|, each root-finding round, the trial point -- would otherwise be a round trip to L2 of its
+  // own: 15 us per call at F = 1000).  PER = 0: any F, from memory.
   __shared__ double sh[2][16];
-  __shared__ double s_a, s_b;
+  __shared__ double s_r[2];
+  __shared__ OmHead hs;
+  constexpr int HW = (int)(sizeof(OmHead) / 4);
+  constexpr int PR = PER > 0 ? PER : 1;
   const int t = threadIdx.x;
-  auto block_sum2 = [&](double a, double b) {        // -> s_a, s_b on every thread
-    a = wave_sum(a);
-    b = wave_sum(b);
+  double r_om[2][PR], r_g[2][PR], r_h[2][PR];
+  if (t < HW) reinterpret_cast<int*>(&hs)[t] = reinterpret_cast<const int*>(st)[t];
+  double q = 0.0;                                      // this thread's share of sum tq (same round of loads as the head)
+  for (int i = t; i < n_q; i += 1024) q += tq[i];
+  if constexpr (PER > 0) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int f = t + 1024 * k;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const double* set = buf + (size_t)c * 3 * F;
+        r_om[c][k] = f < F ? set[f] : 0.0;
+        r_g[c][k] = f < F ? set[F + f] : 0.0;
+        r_h[c][k] = f < F ? set[2 * F + f] : -1.0;
+      }
+    }
+  }
+  __syncthreads();
+  if (hs.status != 0) return;
+  // -> s_r[0], s_r[1] on every thread.  DPP sums: sixteen wavefronts reducing through __shfl_xor (ds_bpermute) queue
+  // on the CU's one LDS pipe, ~0.5 us per sum (common.h)
+  auto block_sum2 = [&](double a, double b) {
+    a = wave_sum_dpp(a); b = wave_sum_dpp(b);
     if ((t & 63) == 0) { sh[0][t >> 6] = a; sh[1][t >> 6] = b; }
     __syncthreads();
-    if (t == 0) {
-      double x = 0.0, y = 0.0;
-      for (int w = 0; w < 16; ++w) { x += sh[0][w]; y += sh[1][w]; }
-      s_a = x; s_b = y;
+    if (t < 2) {
+      double x = 0.0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) x += sh[t][w];
+      s_r[t] = x;
     }
     __syncthreads();
   };
-  double n2 = 0.0, g2 = 0.0;
-  for (int f = t; f < F; f += 1024) {
-    const double c = fmax(-h[f], 1e-12), st = g[f] / c;
-    n2 += st * st;
-    g2 += g[f] * g[f];
-  }
-  block_sum2(n2, g2);
-  const double nrm = sqrt(s_a);
-  if (t == 0) { out[0] = nrm; out[2] = sqrt(s_b); }
-  double lam = 0.0;
-  if (nrm > radius) {
-    for (int it = 0; it < 40; ++it) {
-      double a = 0.0, b = 0.0;                       // |s|^2 and s.(C + lam)^-1 s
-      for (int f = t; f < F; f += 1024) {
-        const double d = fmax(-h[f], 1e-12) + lam, st = g[f] / d;
-        a += st * st;
-        b += st * st / d;
+  if (hs.pending) {
+    // ---- the trial (or the start point) has been evaluated: S = -1/2 |omega|^2 - (1/m) sum tq
+    const int tr = 1 - hs.cur;
+    const double* set = buf + (size_t)tr * 3 * F;
+    double a = 0.0;
+    if constexpr (PER > 0) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) { const double o = tr ? r_om[1][k] : r_om[0][k]; a += o * o; }
+    } else {
+      for (int i = t; i < F; i += 1024) a += set[i] * set[i];
+    }
+    block_sum2(a, q);
+    if (t == 0) {
+      const double Sn = -0.5 * s_r[0] - s_r[1] / (double)m;
+      if (hs.pending == 2) { hs.cur ^= 1; hs.S = Sn; }
+      else {
+        const double rho = (hs.pred > 0.0) ? (Sn - hs.S) / hs.pred : -1.0;
+        if (rho < 0.25) hs.radius *= 0.25;
+        else if (rho > 0.75 && hs.nrm >= hs.radius) hs.radius = (2.0 * hs.radius < 1000.0) ? 2.0 * hs.radius : 1000.0;
+        if (rho > 0.15) { hs.cur ^= 1; hs.S = Sn; }
+        if (hs.radius < 1e-14) hs.status = 3;
       }
-      __syncthreads();                               // everyone has read s_a / s_b of the previous round
-      block_sum2(a, b);
-      const double sn = sqrt(s_a);
-      if (fabs(sn - radius) <= 1e-12 * radius || !(s_b > 0.0)) break;
-      lam += (s_a / s_b) * ((sn - radius) / radius);
-      if (lam < 0.0) lam = 0.0;
+      hs.pending = 0;
+    }
+    __syncthreads();
+  }
+  const int cur = hs.cur;
+  const double* om = buf + (size_t)cur * 3 * F;
+  const double* g = om + F;
+  const double* h = om + 2 * F;
+  // the accepted set: omega, gradient, c = max(-h, 1e-12)
+  double a_om[PR], a_g[PR], a_c[PR];
+  if constexpr (PER > 0) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      a_om[k] = cur ? r_om[1][k] : r_om[0][k];
+      a_g[k] = cur ? r_g[1][k] : r_g[0][k];
+      a_c[k] = fmax(-(cur ? r_h[1][k] : r_h[0][k]), 1e-12);
     }
   }
-  double pred = 0.0;
-  for (int f = t; f < F; f += 1024) {
-    const double c = fmax(-h[f], 1e-12), st = g[f] / (c + lam);
-    trial[f] = omega[f] + st;
-    pred += g[f] * st - 0.5 * st * (c * st);
+  // body(f, omega_f, g_f, c_f) over this thread's entries (padding entries of the register path: g = 0, c = 1)
+  auto each = [&](auto&& body) {
+    if constexpr (PER > 0) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) body(t + 1024 * k, a_om[k], a_g[k], a_c[k]);
+    } else {
+      for (int f = t; f < F; f += 1024) body(f, om[f], g[f], fmax(-h[f], 1e-12));
+    }
+  };
+  {
+    // ---- |gradient| and the Newton step length at the accepted point (also when the search ends here: the reported
+    // |gradient| belongs to the point that is returned)
+    double n2 = 0.0, g2 = 0.0;
+    each([&](int, double, double gf, double c) { const double sf = gf / c; n2 += sf * sf; g2 += gf * gf; });
+    block_sum2(n2, g2);
+    const double nrm = sqrt(s_r[0]), gn = sqrt(s_r[1]);
+    __syncthreads();
+    if (t == 0) {
+      hs.gn = gn; hs.nrm = nrm;
+      if (hs.status == 0) {
+        if (gn < hs.gtol) hs.status = 1;
+        else if (hs.it >= hs.maxiter) hs.status = 2;
+      }
+    }
+    __syncthreads();
+    if (hs.status == 0) {
+      const double radius = hs.radius;
+      double lam = 0.0;
+      if (nrm > radius) {
+        for (int it = 0; it < 40; ++it) {
+          double a = 0.0, b = 0.0;                       // |s|^2 and s.(C + lam)^-1 s
+          each([&](int, double, double gf, double c) { const double d = c + lam, sf = gf / d; a += sf * sf; b += sf * sf / d; });
+          block_sum2(a, b);
+          const double sa = s_r[0], sb = s_r[1];
+          const double sn = sqrt(sa);
+          __syncthreads();                               // everyone has read s_r before the next round overwrites it
+          if (fabs(sn - radius) <= 1e-12 * radius || !(sb > 0.0)) break;
+          lam += (sa / sb) * ((sn - radius) / radius);
+          if (lam < 0.0) lam = 0.0;
+        }
+      }
+      double* trial = buf + (size_t)(1 - cur) * 3 * F;
+      double pred = 0.0;
+      each([&](int f, double of, double gf, double c) {
+        const double sf = gf / (c + lam);
+        if (f < F) trial[f] = of + sf;
+        pred += gf * sf - 0.5 * sf * (c * sf);
+      });
+      block_sum2(pred, 0.0);
+      if (t == 0) { hs.pred = s_r[0]; hs.it += 1; hs.pending = 1; }
+      __syncthreads();
+    }
   }
+  if (hs.status != 0)
+    each([&](int f, double of, double, double) { if (f < F) omega_out[f] = of; });
   __syncthreads();
-  block_sum2(pred, 0.0);
-  if (t == 0) out[1] = s_a;
+  if (t < HW) reinterpret_cast<int*>(st)[t] = reinterpret_cast<const int*>(&hs)[t];
+  if (hs.status != 0) {
+    __threadfence();
+    if (t < HW && prog.head) prog.head[t] = reinterpret_cast<const int*>(&hs)[t];
+    __threadfence_system();
+    __syncthreads();
+  }
+  if (t == 0 && prog.word)
+    __hip_atomic_store(prog.word, ((unsigned long long)(unsigned)hs.status << 32) | (unsigned)hs.it, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // S (optional, into *d_S_out[0]), grad S and diag(S_hessian) at omega, enqueued only
@@ -585,50 +789,74 @@ int ppbo_rff_omega_map(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, 
   PPBO_REQUIRE(ctx, d_Phi && d_omega, "null pointer");
   PPBO_REQUIRE(ctx, F > 0 && N > 0 && m >= 1 && sigma > 0 && N % (m + 1) == 0 && maxiter >= 0 && gtol >= 0, "sizes");
   hipStream_t s = (hipStream_t)stream;
-  // omega / gradient / Hessian diagonal of the accepted point and of the trial point, 4 scalars, pinned read-back
-  double* buf = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH_SMALL, ((size_t)6 * F + 8) * sizeof(double));
-  double* host = (double*)ppbo_pinned(ctx, (64 + 8) * sizeof(double));   // out: 5 of its 8 doubles are used
-  if (!buf || !host) return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "omega_MAP workspace");
-  host += 64;                                    // the first 64 doubles of the pinned block belong to the fit
-  double *om = buf, *g = buf + F, *h = buf + 2 * F, *omt = buf + 3 * F, *gt = buf + 4 * F, *ht = buf + 5 * F;
-  double* out = buf + 6 * F;                     // [0] |unscaled step|, [1] predicted gain, [2] |g|, [3] S(trial)
-  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(om, d_omega, (size_t)F * sizeof(double), hipMemcpyDeviceToDevice, s));
-  double* sc = nullptr;
-  if (int rc = rff_terms_async(ctx, d_Phi, F, N, m, sigma, om, true, g, h, &sc, s)) return rc;
-  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(host, sc, sizeof(double), hipMemcpyDeviceToHost, s));
-  PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
-  double S = host[0], radius = 1.0, gn = INFINITY;
-  bool gn_current = false;                       // gn belongs to the point in `om` (else: to the one before the last acceptance)
-  int it = 0;
-  for (; it < maxiter; ++it) {
-    if (gn_current && gn < gtol) break;          // the accepted point is already stationary: no trial evaluation is paid for
-    // the step from the accepted point and, speculatively, the terms at the trial point (S, gradient, |gradient|^2,
-    // Hessian diagonal): ONE read-back per iteration
-    rff_newton_step_kernel<<<1, 1024, 0, s>>>(om, g, h, F, radius, omt, out);
-    if (int rc = rff_terms_async(ctx, d_Phi, F, N, m, sigma, omt, true, gt, ht, &sc, s)) return rc;
-    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(out + 3, sc, sizeof(double), hipMemcpyDeviceToDevice, s));
-    if (int rc = ppbo_dot_async(ctx, gt, gt, F, out + 4, s)) return rc;
-    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(host, out, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
-    PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
-    const double nrm = host[0], pred = host[1], Sn = host[3];
-    gn = host[2];
-    gn_current = true;
-    if (gn < gtol) break;                        // the accepted point is stationary: the trial is not used
-    const double rho = (pred > 0.0) ? (Sn - S) / pred : -1.0;
-    if (rho < 0.25) radius *= 0.25;
-    else if (rho > 0.75 && nrm >= radius) radius = (2.0 * radius < 1000.0) ? 2.0 * radius : 1000.0;
-    if (rho > 0.15) {
-      std::swap(om, omt); std::swap(g, gt); std::swap(h, ht);
-      S = Sn;
-      gn = std::sqrt(host[4]);                   // |gradient| AT the accepted point (what h_gradnorm reports)
+  const int mblk = m + 1, n_q = N / mblk;
+  constexpr int OM_SPLIT = 32;
+  const int n_split = OM_SPLIT;
+  const int f_per_split = (F + n_split - 1) / n_split;
+  // two (omega, gradient, Hessian diagonal) sets -- the accepted point and the trial -- and the state
+  const size_t st_doubles = (sizeof(OmHead) + 7) / 8;
+  double* buf = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH_SMALL, ((size_t)6 * F + st_doubles + 8) * sizeof(double));
+  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, ((size_t)(n_split + 2) * N + n_q + 8) * sizeof(double));
+  if (!buf || !ws) return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "omega_MAP workspace");
+  OmHead* st = reinterpret_cast<OmHead*>(buf + (size_t)6 * F);
+  double* part = ws;
+  double* a = ws + (size_t)n_split * N;
+  double* h = a + N;
+  double* tq = h + N;
+  // host-mapped progress word + head copy (the ctx's result record block, laid out as the whitened search uses it)
+  PpboHostRecord hr;
+  if (int rc = ppbo_host_record(ctx, &hr)) return rc;
+  static_assert(sizeof(OmHead) <= 16 * sizeof(double), "head copy fits its slot of the host-mapped block");
+  OmProgress prog{reinterpret_cast<unsigned long long*>(hr.d_rec + 24), reinterpret_cast<int*>(hr.d_rec + 4)};
+  volatile unsigned long long* h_word = reinterpret_cast<volatile unsigned long long*>(const_cast<double*>(hr.h_rec) + 24);
+  const OmHead* h_head = reinterpret_cast<const OmHead*>(const_cast<double*>(hr.h_rec) + 4);
+  *h_word = 0;                          // nothing of this ctx is in flight that could write it (one search per ctx at a time)
+  om_init_kernel<<<1, 1, 0, s>>>(st, maxiter, gtol);
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(buf, d_omega, (size_t)F * sizeof(double), hipMemcpyDeviceToDevice, s));   // set 0 = the start point (cur = 1)
+  auto enqueue_slot = [&]() {
+    om_phiT_kernel<<<dim3((N + 255) / 256, n_split), 256, 0, s>>>(st, d_Phi, F, N, buf, f_per_split, part);
+    om_weights_kernel<OM_SPLIT><<<(n_q + 3) / 4, 256, 0, s>>>(st, part, N, mblk, n_q, sigma, tq, a, h);
+    om_rows_kernel<<<(F + 3) / 4, 256, 0, s>>>(st, d_Phi, F, N, mblk, buf, a, h);
+    if (F <= 1024) om_step_kernel<1><<<1, 1024, 0, s>>>(st, buf, F, tq, n_q, m, d_omega, prog);
+    else if (F <= 2048) om_step_kernel<2><<<1, 1024, 0, s>>>(st, buf, F, tq, n_q, m, d_omega, prog);
+    else if (F <= 4096) om_step_kernel<4><<<1, 1024, 0, s>>>(st, buf, F, tq, n_q, m, d_omega, prog);
+    else om_step_kernel<0><<<1, 1024, 0, s>>>(st, buf, F, tq, n_q, m, d_omega, prog);
+  };
+  constexpr int OM_AHEAD = 4;
+  int enq = 0, status = 0;
+  bool synced = false;
+  auto t_last = std::chrono::steady_clock::now();
+  unsigned long long last_word = 0;
+  for (unsigned spins = 0;; ++spins) {
+    const unsigned long long w = *h_word;
+    status = (int)(w >> 32);
+    if (status != 0) break;
+    const int done = (int)(w & 0xffffffffu);      // slot k's step kernel reports it = k + 1 (slot 0 evaluates the start point)
+    if (enq - done < OM_AHEAD && enq < maxiter + 2) {
+      enqueue_slot();
+      ++enq;
+      continue;
     }
-    if (radius < 1e-14) { ++it; break; }
+    __builtin_ia32_pause();
+    if (w != last_word) { last_word = w; t_last = std::chrono::steady_clock::now(); }
+    else if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t_last > std::chrono::seconds(5)) {
+      PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));      // no progress word for seconds: read the state the ordinary way
+      synced = true;
+      break;
+    }
   }
-  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(d_omega, om, (size_t)F * sizeof(double), hipMemcpyDeviceToDevice, s));
-  PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
-  if (h_S) *h_S = S;
-  if (h_gradnorm) *h_gradnorm = gn;
-  if (h_iterations) *h_iterations = it;
+  PPBO_LAUNCH_CHECK(ctx);
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  OmHead head;
+  if (synced && (int)(*h_word >> 32) == 0) {
+    PPBO_HIP_CHECK(ctx, hipMemcpy(&head, st, sizeof(OmHead), hipMemcpyDeviceToHost));
+    if (head.status == 0) return ppbo_set_error(ctx, (int)hipErrorUnknown, "the omega_MAP search made no progress");
+  } else {
+    std::memcpy(&head, h_head, sizeof(OmHead));
+  }
+  if (h_S) *h_S = head.S;
+  if (h_gradnorm) *h_gradnorm = head.gn;
+  if (h_iterations) *h_iterations = head.it;
   return 0;
 }
 
