@@ -314,7 +314,7 @@ def main():
     def fit_once(whitened=True):
         """Sigma, Sigma^-1 (+ the Cholesky factor), f_MAP from the stored start, Lambda_MAP / G: the work of
         update_Sigma + update_Sigma_inv + update_fMAP(1 trial) + the posterior (src/gp_model.py:91-117).
-        whitened=True: ONE library call (ppbo_gp_fit: Sigma^-1 on a side stream behind the search, one host wait);
+        whitened=True: ONE library call (ppbo_gp_fit: everything enqueued on one stream, one host wait);
         whitened=False: the exact trust-region Newton on f alone (rounds 1-2's fit), call by call, timed beside it."""
         if whitened:
             r = eng.gp_fit(Xd, th, kern, m, f_init, gtol=1e-4)
@@ -649,7 +649,7 @@ def main():
             "gp_fit_ms": gp_fit_ms, "gp_fit_ms_runs": fit_runs, "gp_fit_start": fit_start, "gp_fit_iterations": st["iterations"],
             "gp_fit_cholesky": st["n_cholesky"],
             "replicated_fit_bitwise_equal": replicated_equal,
-            "gp_fit_method": "ppbo_gp_fit: one call = Gram, Cholesky, Sigma^-1 (side stream), whitened L-BFGS (z = L^-1 f; "
+            "gp_fit_method": "ppbo_gp_fit: one call = Gram, Cholesky, triangular inverse, Sigma^-1, whitened L-BFGS (z = L^-1 f; "
                              "trust-region finisher only if it does not end on |grad_f T| < gtol), posterior",
             "gp_fit_lbfgs": {"iterations": st["lbfgs_iterations"], "evals": st["lbfgs_evals"], "status": st["lbfgs_status"]},
             "gp_fit_trust_region_only": None if tr_st is None else {

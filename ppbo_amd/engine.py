@@ -376,7 +376,7 @@ class Engine:
                start_is_whitened=False, want_Sigma=True, want_Linv=False, want_posterior=True):
         """One whole GP fit in one library call (ppbo_gp_fit): Sigma, its Cholesky factor and inverse, f_MAP from one
         start by the whitened search, and the posterior state -- the work of update_Sigma + update_Sigma_inv +
-        update_fMAP + the posterior (src/gp_model.py:91-117) with Sigma^-1 formed on a side stream behind the search and
+        update_fMAP + the posterior (src/gp_model.py:91-117), everything enqueued behind each other on one stream with
         ONE host wait.  start_is_whitened: f_init holds z0 and the start is the prior draw L z0.
         Returns dict(Sigma, Sigma_inv, L, Linv, fMAP, post, stats, info); info = 2 (with post = None) when
         Sigma^-1 - Lambda_MAP is not positive definite (raises NotPositiveDefinite when Sigma itself is not)."""
