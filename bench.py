@@ -573,9 +573,10 @@ def main():
         eng.profile(False)
         Ml = B * G
         mb = m + 1
-        # executed MFMA flops: Y = G K* over 128-row tiles cut at the end of the tile's last star (the GEMM's K limit),
-        # and the covariance's data term: (lower-triangle tiles of the ceil(G/16)^2 grid) x 2 products x N rows
-        y_flops = sum(2.0 * 128 * Ml * min(N, -(-((bt + 1) * 128) // mb) * mb) for bt in range(-(-N // 128)))
+        # executed MFMA flops: Y = G K*, every wavefront (32 rows of a 128-row tile) cut at the end of its last star (the
+        # GEMM's per-wavefront K limit, as in quadform_kernel), and the covariance's data term: (lower-triangle tiles of
+        # the ceil(G/16)^2 grid) x 2 products x N rows
+        y_flops = sum(2.0 * 32 * Ml * min(N, -(-((bw + 1) * 32) // mb) * mb) for bw in range(-(-N // 32)))
         nt16 = -(-G // 16)
         cov_tiles = nt16 * (nt16 + 1) // 2 if (mb == 32) else nt16 * nt16
         cov_flops = 2.0 * B * cov_tiles * 2 * 256 * N

@@ -9,7 +9,8 @@ struct GemmArgs {
   int M, N, K;
   double alpha, beta;
   int lower_only;   // skip output tiles strictly above the diagonal
-  int khi_mode;     // 0: K   1: A block-lower-triangular (k < roundup(m0+128, tri_block))   2: k < min(m0,n0)+128
+  int khi_mode;     // 0: K   1: A block-lower-triangular (k < roundup(m0+128, tri_block); each wavefront stops at the end of the
+                    //           block of ITS last row, as quadform_kernel does)   2: k < min(m0,n0)+128
   int klo_mode;     // 0: 0   1: k >= max(m0, n0)   2: k >= n0
   int tri_block;
   int nt_chunk;     // > 0 (128 x 128-tile configuration, no batch): tiles are walked in chunks of nt_chunk column tiles -- all

@@ -148,13 +148,15 @@ def test_device_normal_draws(eng):
         eng._check(eng.lib.ppbo_randn(eng.ctx, 1, None, 10, eng._stream()), "ppbo_randn")
 
 
-def test_rff_omega_map_entry_point(eng):
+@pytest.mark.parametrize("F", [70, 1500, 3000, 4500])
+def test_rff_omega_map_entry_point(eng, F):
     """ppbo_rff_omega_map on a small random basis: lands on a stationary point of S (|grad S| < gtol, every Hessian
-    diagonal entry negative there: a maximum), a second call from the result is a no-op, bad sizes are refused."""
+    diagonal entry negative there: a maximum), a second call from the result is a no-op, bad sizes are refused.
+    The feature counts cover every variant of the step kernel (vectors in 1, 2, 4 registers per thread; from memory)."""
     rng = np.random.default_rng(2)
-    m, n_q, F = 5, 9, 70
+    m, n_q = 5, 9
     N = n_q * (m + 1)
-    Phi = rng.standard_normal((F, N)) * 0.2
+    Phi = rng.standard_normal((F, N)) * 0.2 * np.sqrt(70.0 / F)
     om, S, gn, it = eng.rff_omega_map(Phi, rng.standard_normal(F), m, 0.3, maxiter=500, gtol=1e-6)
     assert gn < 1e-6 and 0 < it < 500
     S1, g1, h1 = eng.rff_terms(Phi, om, m, 0.3)
