@@ -120,6 +120,7 @@ int ppbo_ctx_create(int device, ppbo_ctx** out) {
   if (c->qf_variant < 0 || c->qf_variant > 5) c->qf_variant = 0;
   c->qf_order = env_int("PPBO_QF_ORDER", 514);
   c->line_y_chunk = env_int("PPBO_LINE_Y_CHUNK", 0);
+  c->syrk_cfg = env_int("PPBO_SYRK_CFG", 0);
   c->potrf_gen = env_int("PPBO_POTRF_GEN", 3);
   c->rff_nt = env_int("PPBO_RFF_NT", 0);
   c->gram_variant = env_int("PPBO_GRAM_VARIANT", -1);

@@ -36,6 +36,7 @@ struct ppbo_ctx {
   std::vector<const void*> lds_raised;
   // tuning knobs, read from the environment once per ctx (ppbo_ctx_create); defaults = measured best
   int qf_variant = 2, qf_order = 514, potrf_gen = 3, rff_nt = 0, gram_variant = -1, rff_score_mfma = 1;
+  int syrk_cfg = 0;       // PPBO_SYRK_CFG: tile configuration of Sigma^-1 = Linv^T Linv (0 = by size; 1 / 2 / 3 = 128 / 64 / 32)
   int line_y_chunk = 0;   // PPBO_LINE_Y_CHUNK: column tiles per chunk of Y = G K* in the line acquisition (0 = chosen by size)
   ppbo_dist_state* dist = nullptr;   // set by ppbo_dist_init
   // host-mapped (pinned, device-visible) result record: [0] value, [1] index as a double, [2] the epoch flag the

@@ -116,6 +116,9 @@ int launch_cfg(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, hipStre
 
 int ppbo_gemm_launch(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return 0;
+  if (g.force_cfg == 1) return launch_cfg<GCBig>(ctx, g, transA, transB, s);
+  if (g.force_cfg == 2) return launch_cfg<GCSmall>(ctx, g, transA, transB, s);
+  if (g.force_cfg == 3) return launch_cfg<GCTiny>(ctx, g, transA, transB, s);
   // big tiles only when they still give every CU several workgroups
   const long long big_tiles = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.batch > 1 ? g.batch : 1) /
                               (g.lower_only ? 2 : 1);

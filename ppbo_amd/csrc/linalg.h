@@ -17,6 +17,7 @@ struct GemmArgs {
                     // row tiles of a chunk, longest K range first, before the next chunk -- so that the chunk's slice
                     // of B is re-read from the Infinity Cache instead of HBM once per row tile (the order of
                     // quadform_kernel); 0: row-tile-major as launched
+  int force_cfg;                  // 0: tile configuration by size | 1: 128 x 128 | 2: 64 x 64 | 3: 32 x 32
   int batch;                      // grid.y; operand b lives at base + b*stride (elements); 0/1 = single
   long long strideA, strideB, strideC;
 };

@@ -1135,12 +1135,16 @@ __global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ 
 }
 
 // d_Ainv = Linv^T Linv for a lower-triangular Linv: only the tiles of the lower triangle are computed (the K range of a
-// tile starts at its row), the upper triangle is their mirror image -- half the flops of the full product this
-// replaced (157 -> ~90 us at N = 2048), and exactly symmetric
+// tile starts at its row), the upper triangle is their mirror image (exactly symmetric).  Up to N = 3072 the product runs on
+// 32 x 32 tiles: it has few output tiles and long K ranges, so with 64 x 64 tiles (two wavefronts per SIMD at N = 2048)
+// every chunk waits for its one-chunk-ahead prefetch -- 158 us for 3.1 GF; 32 x 32 tiles put eight wavefronts on a SIMD:
+// 90 us.  Splitting K into windows summed by the mirror pass was measured too (profiles/r04_syrk_inverse_variants.txt):
+// no gain on any tile size.
 int ppbo_syrk_inverse_async(ppbo_ctx* ctx, const double* d_Linv, int N, double* d_Ainv, hipStream_t s) {
   GemmArgs g{};
   g.A = d_Linv; g.lda = N; g.B = d_Linv; g.ldb = N; g.C = d_Ainv; g.ldc = N;
   g.M = N; g.N = N; g.K = N; g.alpha = 1.0; g.beta = 0.0; g.klo_mode = 1; g.tri_block = 1; g.lower_only = 1;
+  g.force_cfg = ctx->syrk_cfg > 0 ? ctx->syrk_cfg : (N <= 3072 ? 3 : 0);
   if (int rc = ppbo_gemm_launch(ctx, g, 1, 0, s)) return rc;
   const int nt = (N + 31) / 32;
   mirror_lower_kernel<<<nt * (nt + 1) / 2, 256, 0, s>>>(d_Ainv, N, N);
