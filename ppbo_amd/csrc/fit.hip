@@ -439,7 +439,8 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
                                            double* __restrict__ zt, double* __restrict__ d, const double* u,
                                            const double* v, const double* beta, const double* tq,
                                            double* __restrict__ basis, long long* dbg = nullptr,
-                                           WhProgress prog = WhProgress{nullptr, nullptr}) {
+                                           WhProgress prog = WhProgress{nullptr, nullptr},
+                                           const double* __restrict__ dots = nullptr, int n_parts = 0) {
   // verbose >= 2: wall_clock64 stamps of the phases of evaluations 3..9 (tools/fit_whitened.py <cfg> <gtol> 2)
 #define LSTAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = wall_clock64(); } while (0)
   constexpr int HW = (int)(sizeof(WhHead) / 4);
@@ -464,7 +465,41 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
   const int first = hs.first, need_gf = hs.need_gf;
   double* gcur = basis + (size_t)(2 * LB_H) * N;
   const double c1 = 1e-4, c2 = 0.9, eps_f = 1e-13;
-  // ---- pass 1
+  // ---- pass 1: the inner products.  When the launch that finished u left them as rows of partial sums (PpboDotsOut:
+  // one row per workgroup of that launch), they are only added up here -- 32 lanes per value, fixed order -- instead
+  // of being formed by this ONE workgroup from 23 N-vectors (4.6 + 2.6 us of the kernel's ~17 at N = 2048)
+  if (dots && n_parts > 0) {
+    static_assert(8 + LB_NB <= 31 && NT == 1024, "32 values x 32 lanes");
+    __shared__ double stage[32];
+    const int k = tid >> 5, l32 = tid & 31;
+    double sacc = 0.0;
+    if (k < 8 + LB_NB) {
+      for (int p = l32; p < n_parts; p += 32) sacc += dots[(size_t)p * PPBO_DOTS_STRIDE + k];
+    } else if (k == 31) {
+      for (int q = l32; q < n_q; q += 32) sacc += tq[q];
+    }
+    const double rs = dpp_add(dpp_add(dpp_add(dpp_add(sacc, 0), 1), 2), 3);       // every lane: the sum of its row of 16
+    double r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      r[q] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rs), 16 * q),
+                              __builtin_amdgcn_readlane(__double2loint(rs), 16 * q));
+    if ((tid & 63) == 0) { stage[2 * (tid >> 6)] = r[0] + r[1]; stage[2 * (tid >> 6) + 1] = r[2] + r[3]; }
+    __syncthreads();
+    if (tid < NA) {
+      // out: zz, tsum, gf2, sy, ss, yy, gt.d | gt.b_l | gt.gt   <-   row: zz, gf2, sy, ss, yy, gt.d, gt.gt, -, gt.b_l
+      int src;
+      if (tid == 0) src = 0;
+      else if (tid == 1) src = 31;
+      else if (tid < 7) src = tid - 1;
+      else if (tid < 7 + LB_NB) src = 8 + (tid - 7);
+      else src = 6;
+      out[tid] = stage[src];
+    }
+    __syncthreads();
+    LSTAMP(2);
+    LSTAMP(3);
+  } else {
   double acc[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) acc[k] = 0.0;
@@ -484,6 +519,7 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
   LSTAMP(2);
   lb_block_sum<NA, NT>(acc, red, red2, out);
   LSTAMP(3);
+  }
   // ---- the judgement (thread 0)
   if (tid == 0) {
     const double phi_t = 0.5 * out[0] + out[1] / (double)m;
@@ -697,8 +733,9 @@ __global__ __launch_bounds__(LB_T) void lbfgs_step_kernel(WhState* __restrict__ 
                                                           const double* __restrict__ v,
                                                           const double* __restrict__ beta,
                                                           const double* __restrict__ tq, double* __restrict__ basis,
-                                                          long long* dbg, WhProgress prog) {
-  lbfgs_step<LB_T>(st, N, m, n_q, z, zt, d, u, v, beta, tq, basis, dbg, prog);
+                                                          long long* dbg, WhProgress prog,
+                                                          const double* __restrict__ dots, int n_parts) {
+  lbfgs_step<LB_T>(st, N, m, n_q, z, zt, d, u, v, beta, tq, basis, dbg, prog, dots, n_parts);
 }
 
 
@@ -741,38 +778,43 @@ __global__ __launch_bounds__(256) void beta_lt_kernel(const int* __restrict__ st
   if (blockIdx.x == 0)
     for (int i = threadIdx.x; i < N; i += 256) beta[i] = sb[i];
   const int i = blockIdx.x * 4 + wv;
-  if (i >= N) return;
-  const double* ur = U + (size_t)i * N;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int k = (i & ~1) + 2 * lane;          // rows are 16-byte aligned (N even); entries left of the diagonal are zero
-  for (; k + 128 < N; k += 256) {
-    const double2 u0 = *reinterpret_cast<const double2*>(ur + k), b0 = *reinterpret_cast<const double2*>(sb + k);
-    const double2 u1 = *reinterpret_cast<const double2*>(ur + k + 128), b1 = *reinterpret_cast<const double2*>(sb + k + 128);
-    a0 += u0.x * b0.x; a1 += u0.y * b0.y; a2 += u1.x * b1.x; a3 += u1.y * b1.y;
+  const bool row_ok = i < N;
+  double su = 0.0, sv = 0.0;
+  const int want_v = *need_gf;
+  if (row_ok) {
+    const double* ur = U + (size_t)i * N;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int k = (i & ~1) + 2 * lane;          // rows are 16-byte aligned (N even); entries left of the diagonal are zero
+    for (; k + 128 < N; k += 256) {
+      const double2 u0 = *reinterpret_cast<const double2*>(ur + k), b0 = *reinterpret_cast<const double2*>(sb + k);
+      const double2 u1 = *reinterpret_cast<const double2*>(ur + k + 128), b1 = *reinterpret_cast<const double2*>(sb + k + 128);
+      a0 += u0.x * b0.x; a1 += u0.y * b0.y; a2 += u1.x * b1.x; a3 += u1.y * b1.y;
+    }
+    for (; k < N; k += 128) {
+      const double2 u0 = *reinterpret_cast<const double2*>(ur + k), b0 = *reinterpret_cast<const double2*>(sb + k);
+      a0 += u0.x * b0.x; a1 += u0.y * b0.y;
+    }
+    su = wave_sum_dpp((a0 + a1) + (a2 + a3));
+    if (lane == 0) u[i] = su;
+    if (want_v) {
+      // v_i = (Sigma^-1 f)_i for the |grad_f| rule, wanted only near the end: f is in LDS already, and a launch of its
+      // own costs its 4-5 us in EVERY slot, gated off or not
+      const double* sr = Sinv + (size_t)i * N;
+      a0 = a1 = a2 = a3 = 0.0;
+      k = 2 * lane;
+      for (; k + 128 < N; k += 256) {
+        const double2 u0 = *reinterpret_cast<const double2*>(sr + k), b0 = *reinterpret_cast<const double2*>(sf + k);
+        const double2 u1 = *reinterpret_cast<const double2*>(sr + k + 128), b1 = *reinterpret_cast<const double2*>(sf + k + 128);
+        a0 += u0.x * b0.x; a1 += u0.y * b0.y; a2 += u1.x * b1.x; a3 += u1.y * b1.y;
+      }
+      for (; k < N; k += 128) {
+        const double2 u0 = *reinterpret_cast<const double2*>(sr + k), b0 = *reinterpret_cast<const double2*>(sf + k);
+        a0 += u0.x * b0.x; a1 += u0.y * b0.y;
+      }
+      sv = wave_sum_dpp((a0 + a1) + (a2 + a3));
+      if (lane == 0) v[i] = sv;
+    }
   }
-  for (; k < N; k += 128) {
-    const double2 u0 = *reinterpret_cast<const double2*>(ur + k), b0 = *reinterpret_cast<const double2*>(sb + k);
-    a0 += u0.x * b0.x; a1 += u0.y * b0.y;
-  }
-  const double su = wave_sum_dpp((a0 + a1) + (a2 + a3));
-  if (lane == 0) u[i] = su;
-  if (*need_gf == 0) return;
-  // v_i = (Sigma^-1 f)_i for the |grad_f| rule, wanted only near the end: f is in LDS already, and a launch of its
-  // own costs its 4-5 us in EVERY slot, gated off or not
-  const double* sr = Sinv + (size_t)i * N;
-  a0 = a1 = a2 = a3 = 0.0;
-  k = 2 * lane;
-  for (; k + 128 < N; k += 256) {
-    const double2 u0 = *reinterpret_cast<const double2*>(sr + k), b0 = *reinterpret_cast<const double2*>(sf + k);
-    const double2 u1 = *reinterpret_cast<const double2*>(sr + k + 128), b1 = *reinterpret_cast<const double2*>(sf + k + 128);
-    a0 += u0.x * b0.x; a1 += u0.y * b0.y; a2 += u1.x * b1.x; a3 += u1.y * b1.y;
-  }
-  for (; k < N; k += 128) {
-    const double2 u0 = *reinterpret_cast<const double2*>(sr + k), b0 = *reinterpret_cast<const double2*>(sf + k);
-    a0 += u0.x * b0.x; a1 += u0.y * b0.y;
-  }
-  const double sv = wave_sum_dpp((a0 + a1) + (a2 + a3));
-  if (lane == 0) v[i] = sv;
 }
 
 // U = L^T (upper triangle, zero below; row pitch N); 32 x 32 tiles through LDS
@@ -1185,13 +1227,18 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
   // workspace: state | basis [LB_NB][N] | z zt d u v beta ft rowsq | tq
   const size_t st_doubles = (sizeof(WhState) + 7) / 8 + 8;
   const size_t nvec = (size_t)LB_NB + 8;
-  double* base = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LBFGS, (st_doubles + nvec * N + n_q + 64) * sizeof(double));
+  const size_t dot_rows = (size_t)(N + 15) / 16 + 1;     // rows of partial inner products (PpboDotsOut): one per workgroup of the u launch
+  double* base = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_LBFGS, (st_doubles + nvec * N + n_q + 64 + dot_rows * PPBO_DOTS_STRIDE) * sizeof(double));
   if (!base) return (int)hipErrorOutOfMemory;
   WhState* st = (WhState*)base;
   double* basis = base + st_doubles;
   double* z = basis + (size_t)LB_NB * N;
   double *zt = z + N, *dd = zt + N, *u = dd + N, *v = u + N, *beta = v + N, *ft = beta + N, *rowsq = ft + N;
   double* tq = rowsq + N;
+  double* dot_part = tq + n_q + 64;
+  PpboDotsOut dots;
+  dots.zt = zt; dots.z = z; dots.gcur = basis + (size_t)(2 * LB_H) * N; dots.d = dd; dots.v = v; dots.beta = beta;
+  dots.basis = basis; dots.nb = LB_NB; dots.partial = dot_part;
   // host-mapped progress word + head copy (the ctx's result record block: doubles [4, 4 + 16) hold the head, [24] the word)
   PpboHostRecord hr;
   if (int rc = ppbo_host_record(ctx, &hr)) return rc;
@@ -1235,15 +1282,17 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
   }
   auto enqueue_slot = [&]() -> int {
     bool v_done = false;                // v = Sigma^-1 f rode along with the u launch
+    int n_parts = 0;                    // > 0: the u launch left the judgement's inner products as that many rows of partial sums
     if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, zt, ft, 0, 1, s, run)) return rc;                  // f = L zt
     if (fused) {
       beta_lt_kernel<<<(N + 3) / 4, 256, blds, s>>>(&st->status, ft, N, mblk, n_q, sigma, U, beta, tq, u, &st->need_gf,
                                                     d_Sigma_inv, v);
-      v_done = true;
+      v_done = true;              // (the judgement's inner products stay with the step kernel here: at these sizes its one
+                                  // workgroup forms them in ~2 us, and rows of partial sums from this launch cost as much)
     } else {
       // u = L^T beta(f): beta rebuilt inside the product's first pass where the star size allows (m = 31: yes)
       const int rcb = ppbo_gemvT_beta_async(ctx, d_L, N, ldl, ft, mblk, sigma, u, beta, tq, s, run, d_Sigma_inv, N, v,
-                                            run_gf);
+                                            run_gf, dots, &n_parts);
       if (rcb > 1) return rcb;
       v_done = rcb == 0;
       if (rcb == 1) {
@@ -1253,7 +1302,7 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
     }
     if (!v_done)
       if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, ft, v, 0, 0, s, run_gf)) return rc;        // v = Sigma^-1 f
-    lbfgs_step_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, v, beta, tq, basis, dbg, prog);
+    lbfgs_step_kernel<<<1, LB_T, 0, s>>>(st, N, m, n_q, z, zt, dd, u, v, beta, tq, basis, dbg, prog, dot_part, n_parts);
     return 0;
   };
   int enq = 0, status = 0, evals = 0;

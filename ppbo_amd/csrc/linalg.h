@@ -57,6 +57,16 @@ struct PpboGate {
 #endif
 };
 
+// Optional by-product of the launch that finishes u = L^T beta in the whitened f_MAP search: the inner products the
+// judgement of the trial point needs, as one row of partial sums per workgroup (summed, in a fixed order, by the
+// judgement's one workgroup).  Row layout (PPBO_DOTS_STRIDE doubles): [0] zt.zt  [1] |v - beta|^2  [2] s.y  [3] s.s
+// [4] y.y  [5] gt.d  [6] gt.gt  [8 + l] gt.b_l  with gt = zt - u, s = zt - z, y = gt - gcur.
+constexpr int PPBO_DOTS_STRIDE = 32;
+struct PpboDotsOut {
+  const double *zt = nullptr, *z = nullptr, *gcur = nullptr, *d = nullptr, *v = nullptr, *beta = nullptr, *basis = nullptr;
+  int nb = 0;                 // basis vectors [nb][N], nb <= PPBO_DOTS_STRIDE - 8
+  double* partial = nullptr;  // [n_part][PPBO_DOTS_STRIDE]; null: no by-product
+};
 // y = T x (trans=0) or y = T^T x (trans=1) for a lower-triangular (lower=1) or full N x N matrix
 int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const double* d_x, double* d_y, int trans,
                     int lower, hipStream_t s, PpboGate gate = PpboGate());
@@ -67,6 +77,6 @@ int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const doub
 int ppbo_gemvT_beta_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, const double* d_f, int mblk, double sigma,
                           double* d_u, double* d_beta, double* d_tq, hipStream_t s, PpboGate gate = PpboGate(),
                           const double* d_R = nullptr, int ldr = 0, double* d_rv = nullptr,
-                          PpboGate rider_gate = PpboGate());
+                          PpboGate rider_gate = PpboGate(), PpboDotsOut dots = PpboDotsOut(), int* n_dot_parts = nullptr);
 // out[0] = sum_i x_i y_i  (deterministic single-block reduction)
 int ppbo_dot_async(ppbo_ctx* ctx, const double* d_x, const double* d_y, int N, double* d_out, hipStream_t s);

@@ -880,6 +880,62 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const double* __restrict
   }
 }
 
+// sum_slabs_kernel (lower = 1, no y0) that also leaves the workgroup's row of PpboDotsOut partial sums over its 16 columns
+__global__ __launch_bounds__(256) void sum_slabs_dots_kernel(const double* __restrict__ partial, int n_split, int N,
+                                                             double* __restrict__ y, PpboGate gate, PpboDotsOut dd) {
+  if (gate.closed()) return;
+  __shared__ double sh[16][17];
+  __shared__ double su[16];
+  const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + c;
+  const int first = ((j / 256) * 256) / GT_ROWS;
+  double s = 0.0;
+  if (j < N) {
+#pragma unroll 4
+    for (int k = first + grp; k < n_split; k += 16) s += partial[(size_t)k * N + j];
+  }
+  sh[grp][c] = s;
+  __syncthreads();
+  if (grp == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += sh[g][c];
+    if (j < N) y[j] = t;
+    su[c] = t;
+  }
+  __syncthreads();
+  // thread (grp, c): products number grp and 16 + grp of column c; the sum over the 16 columns by four xor steps
+  const bool in = j < N;
+  const double zi = in ? dd.zt[j] : 0.0;
+  const double gt = in ? zi - su[c] : 0.0;
+  double p0 = 0.0, p1 = 0.0;
+  if (in) {
+    if (grp < dd.nb) p0 = gt * dd.basis[(size_t)grp * N + j];
+    const int k1 = 16 + grp;                        // 16 .. 31: the remaining basis vectors, then the seven scalars
+    if (k1 < dd.nb) p1 = gt * dd.basis[(size_t)k1 * N + j];
+    else {
+      const int q = k1 - dd.nb;                     // 0 zz, 1 gf2, 2 sy, 3 ss, 4 yy, 5 gt.d, 6 gt.gt
+      if (q == 0) p1 = zi * zi;
+      else if (q == 1) { const double gf = dd.v[j] - dd.beta[j]; p1 = gf * gf; }
+      else if (q == 5) p1 = gt * dd.d[j];
+      else if (q == 6) p1 = gt * gt;
+      else if (q >= 2 && q <= 4) {
+        const double sv = zi - dd.z[j], yv = gt - dd.gcur[j];
+        p1 = (q == 2) ? sv * yv : (q == 3 ? sv * sv : yv * yv);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { p0 += __shfl_xor(p0, o, 64); p1 += __shfl_xor(p1, o, 64); }
+  if (c == 0) {
+    double* row = dd.partial + (size_t)blockIdx.x * PPBO_DOTS_STRIDE;
+    if (grp < dd.nb) row[8 + grp] = p0;
+    const int k1 = 16 + grp;
+    if (k1 < dd.nb) row[8 + k1] = p1;
+    else if (k1 - dd.nb < 7) row[k1 - dd.nb] = p1;
+  }
+}
+
 __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x, const double* __restrict__ y,
                                                    int N, double* __restrict__ out) {
   __shared__ double sh[16];
@@ -1074,7 +1130,7 @@ int ppbo_gemv_rect_async(ppbo_ctx* ctx, const double* d_T, int rows, int cols, i
 // (nothing enqueued) when the star size does not allow it: the caller then runs laplace_kernel + ppbo_gemv_async
 int ppbo_gemvT_beta_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, const double* d_f, int mblk, double sigma,
                           double* d_u, double* d_beta, double* d_tq, hipStream_t s, PpboGate gate, const double* d_R,
-                          int ldr, double* d_rv, PpboGate rider_gate) {
+                          int ldr, double* d_rv, PpboGate rider_gate, PpboDotsOut dots, int* n_dot_parts) {
   if (mblk % GT_ROWS != 0 || mblk > 64 || N % mblk != 0) return 1;
   const int n_split = (N + GT_ROWS - 1) / GT_ROWS;
   double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, (size_t)n_split * N * sizeof(double));
@@ -1083,7 +1139,13 @@ int ppbo_gemvT_beta_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, cons
   const int rider_y = d_R ? ((N + 3) / 4 + gx - 1) / gx : 0;      // extra workgroup rows: four rows of R per workgroup
   gemvT_beta_partial_kernel<<<dim3(gx, n_split + rider_y), 256, 0, s>>>(d_L, N, ldl, d_f, mblk, sigma, part, d_beta,
                                                                         d_tq, gate, n_split, d_R, ldr, d_rv, rider_gate);
-  sum_slabs_kernel<<<(N + 15) / 16, 256, 0, s>>>(part, n_split, N, nullptr, d_u, 1, gate);
+  if (n_dot_parts) *n_dot_parts = 0;
+  if (dots.partial && dots.nb >= 16 && dots.nb <= 25) {       // 32 products per column: nb basis vectors + 7 scalars
+    sum_slabs_dots_kernel<<<(N + 15) / 16, 256, 0, s>>>(part, n_split, N, d_u, gate, dots);
+    if (n_dot_parts) *n_dot_parts = (N + 15) / 16;
+  } else {
+    sum_slabs_kernel<<<(N + 15) / 16, 256, 0, s>>>(part, n_split, N, nullptr, d_u, 1, gate);
+  }
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
