@@ -337,8 +337,11 @@ int ppbo_rff_terms(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, doub
  * (in: start, out: omega_MAP).  The reference hands -S to SciPy's trust-exact; S_hessian is diagonal, so the trust
  * region subproblem has the closed form s_i = g_i / (max(-h_i, 1e-12) + lam) with lam = 0 when the Newton step fits
  * and the More-Sorensen root of |s(lam)| = radius otherwise, under SciPy's radius rules (x1/4 below rho = 1/4, x2
- * above 3/4 on the boundary, accept above 0.15).  omega, gradient and Hessian diagonal stay
- * on the device; the host reads four scalars per iteration.  Stops on |grad S| < gtol, maxiter, or a collapsed radius. */
+ * above 3/4 on the boundary, accept above 0.15).  The whole loop is device-resident: omega, gradient, Hessian diagonal
+ * AND the trust region's state stay on the device, one workgroup judges each trial and forms the next (four launches per
+ * iteration), the host only keeps a few iterations enqueued ahead of a host-mapped progress word and reads S, |grad S|
+ * and the iteration count once, at the end.  d_omega is written on `stream` (ordered for later work on that stream).
+ * Stops on |grad S| < gtol (h_gradnorm belongs to the point returned), maxiter, or a collapsed radius. */
 int ppbo_rff_omega_map(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, double sigma, double* d_omega,
                        int maxiter, double gtol, double* h_S, double* h_gradnorm, int* h_iterations, void* stream);
 
