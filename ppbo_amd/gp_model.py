@@ -318,7 +318,9 @@ class GPModel:
 
     @staticmethod
     def _default_workers(N):
-        return 8 if N <= 1024 else (4 if N <= 2048 else 2)
+        # measured (tools/dev/r4_evidence_workers.py, 20 evidences): N = 512: 76.7 / 32.9 / 26.9 / 27.4 ms with 1 / 4 / 8 / 16
+        # contexts; N = 2048: 214.7 / 86.5 / 76.7 / 67.9 ms -- beyond eight the host's launch rate is the limit
+        return 8 if N <= 2048 else (4 if N <= 4096 else 2)
 
     # ------------------------------------------------------------------ evidence / hyper-parameters
     def _evidence_core(self, eng, theta, f0):
