@@ -146,8 +146,8 @@ class Hsampler:
         trust-region Newton of the reference reduces to per-coordinate safeguarded Newton steps."""
         omega = np.random.randn(self.nFeatures)
         start = time.time()
-        # the whole safeguarded Newton loop runs behind one call (ppbo_rff_omega_map): omega, gradient and Hessian
-        # diagonal stay on the device, four scalars per iteration come back
+        # the whole trust-region loop runs behind one call (ppbo_rff_omega_map) and on the device: omega, gradient,
+        # Hessian diagonal and the region's state stay there, S / |grad S| / the iteration count come back once
         omega, S, gnorm, iters = self.eng.rff_omega_map(self._dPhi, omega, self.m, self.theta[0], maxiter=500, gtol=1e-6)
         self.omega_MAP_stats = {"S": S, "gradnorm": gnorm, "iterations": iters}
         if self.verbose:
