@@ -90,11 +90,16 @@ int ppbo_host_record_wait(ppbo_ctx* ctx, const PpboHostRecord& r, hipStream_t s)
 }
 
 void ppbo_lds_limit(ppbo_ctx* ctx, const void* kernel_fn, int bytes) {
-  for (const void* f : ctx->lds_raised)
-    if (f == kernel_fn) return;
-  // the largest size any caller asks for is fixed per kernel, so one call per kernel and device suffices
+  for (size_t k = 0; k < ctx->lds_raised.size(); ++k)
+    if (ctx->lds_raised[k] == kernel_fn) {
+      if (bytes <= ctx->lds_raised_bytes[k]) return;           // one call per kernel and size class suffices
+      (void)hipFuncSetAttribute(kernel_fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      ctx->lds_raised_bytes[k] = bytes;
+      return;
+    }
   (void)hipFuncSetAttribute(kernel_fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   ctx->lds_raised.push_back(kernel_fn);
+  ctx->lds_raised_bytes.push_back(bytes);
 }
 
 extern "C" {
@@ -121,6 +126,8 @@ int ppbo_ctx_create(int device, ppbo_ctx** out) {
   c->qf_order = env_int("PPBO_QF_ORDER", 514);
   c->line_y_chunk = env_int("PPBO_LINE_Y_CHUNK", 0);
   c->syrk_cfg = env_int("PPBO_SYRK_CFG", 0);
+  c->fit_overlap = env_int("PPBO_FIT_OVERLAP", 1);
+  c->fit_gf_from = env_int("PPBO_FIT_GF_FROM", 8);
   c->potrf_gen = env_int("PPBO_POTRF_GEN", 3);
   c->rff_nt = env_int("PPBO_RFF_NT", 0);
   c->gram_variant = env_int("PPBO_GRAM_VARIANT", -1);
@@ -139,6 +146,9 @@ int ppbo_ctx_destroy(ppbo_ctx* ctx) {
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->hostrec) (void)hipHostFree(ctx->hostrec);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   for (int i = 0; i < ppbo_ctx::PF_COUNT; ++i)
     for (auto& pr : ctx->pf_events[i]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   }

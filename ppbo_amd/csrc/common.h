@@ -34,8 +34,15 @@ struct ppbo_ctx {
   size_t pf_used[PF_COUNT] = {};
   // kernels whose dynamic-LDS limit has been raised on THIS ctx's device (hipFuncSetAttribute is per device)
   std::vector<const void*> lds_raised;
+  std::vector<int> lds_raised_bytes;
   // tuning knobs, read from the environment once per ctx (ppbo_ctx_create); defaults = measured best
   int qf_variant = 2, qf_order = 514, potrf_gen = 3, rff_nt = 0, gram_variant = -1, rff_score_mfma = 1;
+  // ppbo_gp_fit runs the triangular inverse and Sigma^-1 on a second stream beside the first evaluations of the f_MAP
+  // search, which needs only L until the |grad_f| rule is armed (fit.hip)
+  int fit_overlap = 1;    // PPBO_FIT_OVERLAP
+  int fit_gf_from = 8;    // PPBO_FIT_GF_FROM: the first evaluation that may apply the |grad_f| rule in that mode
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int syrk_cfg = 0;       // PPBO_SYRK_CFG: tile configuration of Sigma^-1 = Linv^T Linv (0 = by size; 1 / 2 / 3 = 128 / 64 / 32)
   int line_y_chunk = 0;   // PPBO_LINE_Y_CHUNK: column tiles per chunk of Y = G K* in the line acquisition (0 = chosen by size)
   ppbo_dist_state* dist = nullptr;   // set by ppbo_dist_init

@@ -325,7 +325,8 @@ struct WhState {
                    // failed along steepest descent, 4 non-finite objective at the start, 5 evaluation budget spent
   int evals, iters, hist, head, first, ls, stall, need_gf, max_evals;
   int gf_avail;    // 0: Sigma^-1 f is not available to the judgement (|grad_f| cannot be asked for); always 1 today
-  int pad_;
+  int gf_from;     // the |grad_f| rule is armed from this evaluation on (ppbo_gp_fit with the side stream: Sigma^-1 is
+                   // guaranteed from that slot on -- a fixed number, so the result does not depend on timing)
   double phi, dphi, alpha, gz2, gf2, gate, gtol2, gzbest;
   double B[LB_NB * LB_NB];
   double delta[LB_NB];   // coefficients (over the basis) of the direction behind the current trial point
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const double* __restric
 }
 
 __global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ st, const double* __restrict__ rowsq,
-                                                          int N, double gtol, int max_evals, int gf_avail) {
+                                                          int N, double gtol, int max_evals, int gf_avail, int gf_from) {
   __shared__ double sh[LB_T / 64];
   double s = 0.0;
   for (int i = threadIdx.x; i < N; i += LB_T) s += rowsq[i];
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ 
     double t = 0.0;
     for (int w = 0; w < LB_T / 64; ++w) t += sh[w];
     st->status = 0; st->evals = 0; st->iters = 0; st->hist = 0; st->head = 0; st->first = 1; st->ls = 0;
-    st->stall = 0; st->need_gf = 0; st->max_evals = max_evals; st->gf_avail = gf_avail; st->pad_ = 0;
+    st->stall = 0; st->need_gf = 0; st->max_evals = max_evals; st->gf_avail = gf_avail; st->gf_from = gf_from;
     st->phi = 0.0; st->dphi = 0.0; st->alpha = 0.0; st->gz2 = 0.0; st->gf2 = -1.0;
     st->gate = gtol * sqrt(t);          // |grad_f| < gtol needs |grad_z| < gtol |L|_F
     st->gtol2 = gtol * gtol;
@@ -402,7 +403,7 @@ __device__ __forceinline__ void lb_block_sum(double (&v)[K], double* __restrict_
 // the start and written once at the end -- a thread that loads, computes, stores and loads again from global memory
 // pays ~1 us per dependent access, which made the first version of this function take 25-45 us.
 struct WhHead {
-  int status, evals, iters, hist, head, first, ls, stall, need_gf, max_evals, gf_avail, pad_;
+  int status, evals, iters, hist, head, first, ls, stall, need_gf, max_evals, gf_avail, gf_from;
   double phi, dphi, alpha, gz2, gf2, gate, gtol2, gzbest;
 };
 // Progress of the search as the host sees it: the step kernel stores (status << 32 | evals) into host-mapped memory
@@ -635,7 +636,7 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
     else if (hs.stall >= 3) { hs.status = 2; stop = 1; }
     else if (hs.evals >= hs.max_evals) { hs.status = 5; stop = 1; }
     else if (!(gz2 > 0.0)) { hs.status = isfinite(gz2) ? 1 : 4; stop = 1; }
-    hs.need_gf = hs.gf_avail && sqrt(gz2) < hs.gate;
+    hs.need_gf = hs.gf_avail && hs.evals >= hs.gf_from && sqrt(gz2) < hs.gate;
     hs.hist = hist; hs.head = head; hs.first = 0;
     act[3] = stop;
   }
@@ -1215,6 +1216,8 @@ struct WhitenedExtras {
   const double* d_Linv = nullptr;    // when given: z0 = L^-1 f_init by one triangular product (else L^T (Sigma^-1 f_init))
   bool start_is_z = false;           // d_f_init IS z0
   bool sync_at_end = true;           // false: d_fMAP is only enqueued (the caller synchronises later)
+  hipEvent_t join_event = nullptr;   // when given: Sigma^-1 (and L^-1) are being produced on another stream; the search's
+  int gf_from = 0;                   // stream waits for this event before slot gf_from, the first that may read them
 };
 
 int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m, double sigma,
@@ -1249,7 +1252,7 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
   *h_word = 0;                          // nothing of this ctx is in flight that could write it (one search per ctx at a time)
   PPBO_HIP_CHECK(ctx, hipMemsetAsync(base, 0, (st_doubles + (size_t)LB_NB * N) * sizeof(double), s));
   row_sqnorm_kernel<<<(N + 3) / 4, 256, 0, s>>>(d_L, N, ldl, rowsq);
-  lbfgs_init_kernel<<<1, LB_T, 0, s>>>(st, rowsq, N, gtol, max_evals, 1);
+  lbfgs_init_kernel<<<1, LB_T, 0, s>>>(st, rowsq, N, gtol, max_evals, 1, ex.join_event ? ex.gf_from : 0);
   PPBO_LAUNCH_CHECK(ctx);
   if (ex.start_is_z) {
     PPBO_HIP_CHECK(ctx, hipMemcpyAsync(zt, d_f_init, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1306,7 +1309,7 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
     return 0;
   };
   int enq = 0, status = 0, evals = 0;
-  bool synced = false;
+  bool synced = false, joined = false;
   auto t_last = std::chrono::steady_clock::now();
   unsigned long long last_word = 0;
   for (unsigned spins = 0;; ++spins) {
@@ -1315,6 +1318,10 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
     evals = (int)(w & 0xffffffffu);
     if (status != 0) break;
     if (enq - evals < WH_AHEAD && enq < max_evals + WH_AHEAD) {
+      if (ex.join_event && !joined && enq >= ex.gf_from) {
+        PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(s, ex.join_event, 0));
+        joined = true;
+      }
       if (int rc = enqueue_slot()) return rc;
       ++enq;
       continue;
@@ -1329,6 +1336,7 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
     }
   }
   PPBO_LAUNCH_CHECK(ctx);
+  if (ex.join_event && !joined) PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(s, ex.join_event, 0));   // the finisher, alpha, the posterior need them
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   WhHead head;
   if (synced && (int)(*h_word >> 32) == 0) {
@@ -1454,14 +1462,34 @@ int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, c
     if (int rc = ppbo_gram(ctx, kernel_id, d_X, N, D, theta, shrink, d_Sigma, stream)) return rc;
   if (int rc = ppbo_gram(ctx, kernel_id, d_X, N, D, theta, shrink, d_L, stream)) return rc;
   if (int rc = ppbo_potrf_async(ctx, d_L, N, N, d_info, s)) return rc;
-  if (int rc = ppbo_trtri_async(ctx, d_L, N, N, Li, N, s)) return rc;
+  const bool overlap = ctx->fit_overlap && opts && opts->start_is_whitened != 0 && N >= 1024;
+  hipStream_t s2 = s;
+  if (overlap) {
+    if (!ctx->side_stream) {
+      PPBO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+      PPBO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      PPBO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    s2 = ctx->side_stream;
+    PPBO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));
+    PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+  }
+  if (int rc = ppbo_trtri_async(ctx, d_L, N, N, Li, N, s2)) return rc;
   // Sigma^-1 = L^-T L^-1: the lower triangle on the matrix cores, the upper one mirrored (bitwise symmetric).
-  // (Round 4 also ran this product on a second stream behind the search, which needs only L and L^-1 until its last
-  // evaluations: the GEMM's 1024 short-lived workgroups starve the search's small launches -- a 10 us helper kernel
-  // took 132 us beside it, with a CU mask or a lower stream priority just the same -- so nothing was gained and the
-  // event plumbing went out again: profiles/r04_fit_side_stream.txt.)
-  if (int rc = ppbo_syrk_inverse_async(ctx, Li, N, d_Sigma_inv, s)) return rc;
+  // With a whitened start the search needs only L until its |grad_f| rule is armed, so the triangular inverse and this
+  // product run on the ctx's second stream beside the first evaluations; the search's stream joins them before slot
+  // fit_gf_from, the first evaluation that may apply that rule (a fixed number: the result does not depend on timing).
+  // Round 4 history: with the product on 64 x 64 tiles (1024 long-lived workgroups, 157 us) the search's small launches
+  // starved beside it (profiles/r04_fit_side_stream.txt: no gain); on 32 x 32 tiles (90 us) the two streams do share the
+  // chip: fit 2.49 -> 2.38 ms at N = 2048 (an LDS occupancy cap on the side GEMMs, 1 to 4 workgroups per CU, made no
+  // difference either way).
+  if (int rc = ppbo_syrk_inverse_async(ctx, Li, N, d_Sigma_inv, s2)) return rc;
   WhitenedExtras ex;
+  if (overlap) {
+    PPBO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, s2));
+    ex.join_event = ctx->ev_join;
+    ex.gf_from = ctx->fit_gf_from;
+  }
   ex.d_Linv = Li;
   ex.start_is_z = opts && opts->start_is_whitened != 0;
   ex.sync_at_end = false;

@@ -77,6 +77,34 @@ def test_gp_fit_from_a_whitened_start(eng, golden, name):
     assert np.abs(host(a["fMAP"]) - host(b["fMAP"])).max() <= 1e-4 * np.abs(host(b["fMAP"])).max()
 
 
+def test_gp_fit_second_stream_changes_nothing(eng, golden, monkeypatch):
+    """From N = 1024 on a whitened start lets ppbo_gp_fit form L^-1 and Sigma^-1 on the ctx's second stream beside the
+    first evaluations of the search (PPBO_FIT_OVERLAP, default on).  The search's stream joins them at a FIXED slot, so
+    the result is bitwise the one of a ctx that does everything on one stream, call after call; a budget that ends the
+    search before the join slot still hands the finisher a finished Sigma^-1."""
+    from ppbo_amd.engine import Engine
+    g = golden("c3")
+    X, th, kern, m = g["X"], g["theta"], str(g["kernel"]), int(g["m"])
+    z0 = np.random.default_rng(3).standard_normal(X.shape[0])
+    a = eng.gp_fit(X, th, kern, m, z0, start_is_whitened=True)
+    a2 = eng.gp_fit(X, th, kern, m, z0, start_is_whitened=True)
+    monkeypatch.setenv("PPBO_FIT_OVERLAP", "0")
+    plain = Engine(0)
+    try:
+        b = plain.gp_fit(X, th, kern, m, z0, start_is_whitened=True)
+        assert a["stats"] == b["stats"] == a2["stats"] and a["stats"]["lbfgs_evals"] > 8
+        for key in ("fMAP", "Sigma_inv", "L"):
+            assert np.array_equal(host(a[key]), host(b[key])) and np.array_equal(host(a[key]), host(a2[key])), key
+        assert np.array_equal(host(a["post"].G), host(b["post"].G)) and np.array_equal(host(a["post"].alpha), host(b["post"].alpha))
+        c = eng.gp_fit(X, th, kern, m, z0, start_is_whitened=True, lbfgs_max_evals=5)
+        d = plain.gp_fit(X, th, kern, m, z0, start_is_whitened=True, lbfgs_max_evals=5)
+        assert c["stats"]["lbfgs_status"] == 5 and c["stats"]["converged"] and c["stats"] == d["stats"]
+        assert np.array_equal(host(c["fMAP"]), host(d["fMAP"]))
+        assert np.abs(host(c["fMAP"]) - host(a["fMAP"])).max() <= 1e-4 * np.abs(host(a["fMAP"])).max()
+    finally:
+        plain.close()
+
+
 def test_gp_fit_is_deterministic_and_reusable(eng, golden):
     g = golden("c2")
     X, th, kern, m = g["X"], g["theta"], str(g["kernel"]), int(g["m"])

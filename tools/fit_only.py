@@ -1,5 +1,5 @@
 """One GP fit (Gram, inverse + Cholesky factor, whitened f_MAP search, posterior) a few times -- target for
-rocprofv3 --kernel-trace.   python tools/fit_only.py [c3] [tr|calls]   ('tr' = the trust region alone, rounds 1-2's fit; 'calls' = the whitened fit call by call)"""
+rocprofv3 --kernel-trace.   python tools/fit_only.py [c3] [tr|calls|z]   ('z' = start from a whitened draw z0, the drop-in's default; 'tr' = the trust region alone, rounds 1-2's fit; 'calls' = the whitened fit call by call)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,10 +11,12 @@ g = dict(np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden"
 X = eng.dev(g["X"]); m = int(g["m"]); th = g["theta"]; kern = str(g["kernel"])
 f0 = eng.dev(g["f_init"])
 fused = whitened and not (len(sys.argv) > 2 and sys.argv[2] == "calls")
+zstart = len(sys.argv) > 2 and sys.argv[2] == "z"          # the product's start: z0 ~ N(0, I), f_init = L z0 (GPModel._fit_fused)
+z0 = eng.dev(np.random.default_rng(2).standard_normal(X.shape[0]))
 for rep in range(4):
     if fused:
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        r = eng.gp_fit(X, th, kern, m, f0)
+        r = eng.gp_fit(X, th, kern, m, z0, start_is_whitened=True) if zstart else eng.gp_fit(X, th, kern, m, f0)
         torch.cuda.synchronize(); t3 = time.perf_counter()
         print(f"rep {rep}: total {(t3 - t0) * 1e3:.2f} ms (ppbo_gp_fit, one call)", r["stats"])
         continue
