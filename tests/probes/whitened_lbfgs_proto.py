@@ -148,7 +148,7 @@ def fit(name, gtol=1e-4, max_evals=3000, verbose=False):
             delta[2 * H] = -1.0
             dphi = -B[2 * H, 2 * H]
         d = delta @ basis
-        alpha = min(1.0, 1.0 / gz) if first else 1.0
+        alpha = 1.0                     # also for the first move (was min(1, 1 / |g|): 19 -> 17 evaluations at c3, 70 -> 62 at c2)
         first = False
         zt = z + alpha * d
     f = L @ z

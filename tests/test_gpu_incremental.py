@@ -113,7 +113,8 @@ def test_incremental_replay_matches_cold_refits(golden, method):
     """Same queries and designs, cold (a prior draw per update, the reference's default) vs incremental (bordered
     Sigma^-1 / L^-1 / L, warm start), both at the reference's stopping rule: the same f_MAP to 1e-5 max|f| plus the
     two fits' own Newton gaps, the same mu*, and markedly less work per query: >= 3x fewer factorizations on the
-    trust-region path, >= 1.5x fewer O(N^2) evaluations (and still no factorization) on the whitened path."""
+    trust-region path, >= 1.3x fewer O(N^2) evaluations (and still no factorization) on the whitened path (1.5x until the
+    cold search learnt to open with the unit step: 23-33 evaluations per query cold against 16-21 warm now)."""
     g, cold = _replay(golden, False, method)
     g, inc = _replay(golden, True, method)
     n_init = int(g["n_init"])
@@ -140,7 +141,7 @@ def test_incremental_replay_matches_cold_refits(golden, method):
     if method == "trust-region":
         assert np.median(ratio) >= 3.0, ratio
     else:
-        assert np.median(ratio) >= 1.5, ratio
+        assert np.median(ratio) >= 1.3, ratio
         assert max(k["chol"] for k in inc[n_init:]) <= 2
 
 
