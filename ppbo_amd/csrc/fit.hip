@@ -1461,10 +1461,6 @@ int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, c
   double* Li = d_Linv ? d_Linv : W + nn;     // the posterior reuses this half for R -- after the GEMM below has read it
   // Sigma (kept for the caller) and the matrix the factorization overwrites: the Gram kernel runs twice (8.6 us at
   // N = 2048) instead of once plus a 33 MB device-to-device copy (12 us)
-  if (d_Sigma)
-    if (int rc = ppbo_gram(ctx, kernel_id, d_X, N, D, theta, shrink, d_Sigma, stream)) return rc;
-  if (int rc = ppbo_gram(ctx, kernel_id, d_X, N, D, theta, shrink, d_L, stream)) return rc;
-  if (int rc = ppbo_potrf_async(ctx, d_L, N, N, d_info, s)) return rc;
   const bool overlap = ctx->fit_overlap && opts && opts->start_is_whitened != 0 && N >= 1024;
   hipStream_t s2 = s;
   if (overlap) {
@@ -1474,7 +1470,15 @@ int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, c
       PPBO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     }
     s2 = ctx->side_stream;
-    PPBO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));
+    PPBO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));            // X (and whatever else the caller enqueued) is there
+    PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+  }
+  if (d_Sigma)                                                        // the caller's copy: off the critical path
+    if (int rc = ppbo_gram(ctx, kernel_id, d_X, N, D, theta, shrink, d_Sigma, (void*)s2)) return rc;
+  if (int rc = ppbo_gram(ctx, kernel_id, d_X, N, D, theta, shrink, d_L, stream)) return rc;
+  if (int rc = ppbo_potrf_async(ctx, d_L, N, N, d_info, s)) return rc;
+  if (overlap) {
+    PPBO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));            // the factor is there
     PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
   }
   if (int rc = ppbo_trtri_async(ctx, d_L, N, N, Li, N, s2)) return rc;

@@ -557,7 +557,12 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A,
                                                          int nP, int ntS, double* __restrict__ diag_out,
                                                          int* __restrict__ info, double* __restrict__ fail_pivot) {
   extern __shared__ __attribute__((aligned(16))) double plds[];
-  const int info_in = *info;     // consumed after the first loads are in flight (both parts)
+  // consumed after the first loads are in flight (both parts).  The FIRST step of a factorization does not read the
+  // word, it resets it (and the failed pivot): the thread that would report a failure -- workgroup 0, thread 0 -- does
+  // so first, in program order; a launch of its own for two stores cost 4.4 us per factorization
+  int info_in = 0;
+  if (has_prev) info_in = *info;
+  else if (blockIdx.x == 0 && threadIdx.x == 0) { *info = 0; if (fail_pivot) *fail_pivot = NAN; }
   const int nSW = gridDim.x - nP;
   if ((int)blockIdx.x >= nP) {
     potrf_update_part(A, lda, N, k0, nP, ntS, plds, blockIdx.x - nP, 0, info_in);
@@ -997,7 +1002,7 @@ __global__ void set_int_kernel(int* p, int v, double* fail_pivot) {
 // ctx->potrf_gen (PPBO_POTRF_GEN): 3 (default): potrf_step_kernel; 2: potf2_block + trsm_mfma + gemm64 SYRK
 int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hipStream_t s, double* d_fail_pivot) {
   PpboProfScope pf(ctx, ppbo_ctx::PF_POTRF, s);
-  set_int_kernel<<<1, 1, 0, s>>>(d_info, 0, d_fail_pivot);
+  if (ctx->potrf_gen < 3) set_int_kernel<<<1, 1, 0, s>>>(d_info, 0, d_fail_pivot);   // generation 3: the first step does it
   if (ctx->potrf_gen >= 3) {
     ppbo_lds_limit(ctx, (const void*)potrf_step_kernel, STEP_LDS);
     const int npanel = (N + NB - 1) / NB;

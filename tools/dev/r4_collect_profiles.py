@@ -20,9 +20,9 @@ shutil.copy(os.path.join(S, "kernel_stats.csv"), os.path.join(P, "r04_bench_rocp
 shutil.copy(os.path.join(S, "pmc_hot_kernels.json"), os.path.join(P, "r04_pmc_hot_kernels.json"))
 open(os.path.join(P, "r04_scaling_prediction.txt"), "w").write(clean(os.path.join(S, "scaling.txt")))
 open(os.path.join(P, "r04_fit_kernel_trace.txt"), "w").write(
-    "# rocprofv3 --kernel-trace -- python3 tools/fit_only.py c3 (four ppbo_gp_fit calls), tools/dev/trace_summary.py: per kernel count / avg / min / max (us) and\n"
+    "# rocprofv3 --kernel-trace -- python3 tools/fit_only.py c3 z (four ppbo_gp_fit calls from a whitened start: the two-stream form), tools/dev/trace_summary.py: per kernel count / avg / min / max (us) and\n"
     "# the timeline of the LAST fit; wall clock of the same script without the profiler at the end\n"
-    + clean(os.path.join(S, "fit_trace.txt")) + "\n# wall clock without the profiler (tools/fit_only.py c3):\n" + clean(os.path.join(S, "fit_wall.txt")))
+    + clean(os.path.join(S, "fit_trace.txt")) + "\n# wall clock without the profiler (tools/fit_only.py c3 z):\n" + clean(os.path.join(S, "fit_wall.txt")))
 open(os.path.join(P, "r04_line_acq_kernel_trace.txt"), "w").write(
     "# rocprofv3 --kernel-trace -- python3 tools/dev/r4_line_trace.py: 512 lines x 70 points x 150 draws at C3 through ppbo_line_acq_xi; per kernel stats and the last call's timeline;\n"
     "# wall clock without the profiler and next_query end to end at the C3 shape below\n"

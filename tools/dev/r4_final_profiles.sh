@@ -13,11 +13,11 @@ python bench.py --config c2 --no-secondary > $OUT/bench_c2.json 2> $OUT/bench_c2
 python bench.py --config c4 --no-secondary > $OUT/bench_c4.json 2> $OUT/bench_c4.err
 python bench.py --config c5 --no-secondary --steps 20 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
 python tools/predict_scaling.py > $OUT/scaling.txt 2> $OUT/scaling.err
-python tools/fit_only.py c3 > $OUT/fit_wall.txt 2>&1
+python tools/fit_only.py c3 z > $OUT/fit_wall.txt 2>&1
 python tools/dev/r4_line_trace.py nq > $OUT/line_wall.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-secondary --no-precision-report > $OUT/stats_bench.log 2>&1
-rocprofv3 --kernel-trace --output-format csv -d $OUT/fitprof -- python3 $GRAFT_REPO_ROOT/tools/fit_only.py c3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/fitprof -- python3 $GRAFT_REPO_ROOT/tools/fit_only.py c3 z > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $OUT/lineprof -- python3 $GRAFT_REPO_ROOT/tools/dev/r4_line_trace.py > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/dev/trace_summary.py $OUT/fitprof 260 > $OUT/fit_trace.txt
