@@ -1463,6 +1463,11 @@ int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, c
   // N = 2048) instead of once plus a 33 MB device-to-device copy (12 us)
   const bool overlap = ctx->fit_overlap && opts && opts->start_is_whitened != 0 && N >= 1024;
   hipStream_t s2 = s;
+  // an error return after the fork must not leave the second stream working on buffers the caller may free
+  struct SideGuard {
+    hipStream_t side = nullptr;
+    ~SideGuard() { if (side) (void)hipStreamSynchronize(side); }
+  } side_guard;
   if (overlap) {
     if (!ctx->side_stream) {
       PPBO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
@@ -1470,6 +1475,7 @@ int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, c
       PPBO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     }
     s2 = ctx->side_stream;
+    side_guard.side = s2;
     PPBO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));            // X (and whatever else the caller enqueued) is there
     PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
   }
@@ -1516,6 +1522,7 @@ int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, c
   h2[0] = h2[1] = 0;
   PPBO_HIP_CHECK(ctx, hipMemcpyAsync(h2, d_info, (d_G ? 2 : 1) * sizeof(int), hipMemcpyDeviceToHost, s));
   PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  side_guard.side = nullptr;                      // s has waited for the second stream's event: everything is done
   if (h2[0] != 0) {
     if (h_info) *h_info = 1;
     return ppbo_set_error(ctx, PPBO_ERR_NOT_PD, "Sigma is not positive definite (leading minor %d)", h2[0]);
