@@ -244,12 +244,15 @@ __global__ __launch_bounds__(256) void g_build_kernel(const double* __restrict__
                                                       const double* __restrict__ lam_off, double* __restrict__ G) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const double* r = R + (size_t)blockIdx.y * N;
+  // R is lower triangular and only its 64 x 64 diagonal blocks carry written zeros above the diagonal (the triangular
+  // inverse skipped the memset of the rest): right of this row's block everything counts as zero, unread
+  const int lim = (((int)blockIdx.y >> 6) + 1) << 6;
   if (mblk == 32 && (N & 31) == 0) {
     // a star is exactly one aligned half-wavefront: the observation column's sum over its star comes from the
     // other 31 lanes by shuffles instead of a 31-iteration loop in one lane (which held the whole wavefront:
     // 125 us for 2 x 33 MB at N = 2048)
     const bool in = j < N;            // N % 32 == 0: a half-wavefront is entirely inside or entirely outside
-    const double rj = in ? r[j] : 0.0, ld = in ? lam_diag[j] : 0.0, lo = in ? lam_off[j] : 0.0;
+    const double rj = (in && j < lim) ? r[j] : 0.0, ld = in ? lam_diag[j] : 0.0, lo = in ? lam_off[j] : 0.0;
     const bool obs = (j & 31) == 0;
     double t = obs ? rj * ld : rj * lo;
 #pragma unroll
@@ -260,12 +263,13 @@ __global__ __launch_bounds__(256) void g_build_kernel(const double* __restrict__
   }
   if (j >= N) return;
   const int q0 = (j / mblk) * mblk;
-  double acc = r[j] * lam_diag[j];
+  auto rr = [&](int k) { return k < lim ? r[k] : 0.0; };
+  double acc = rr(j) * lam_diag[j];
   if (j != q0) {
-    acc += r[q0] * lam_off[j];
+    acc += rr(q0) * lam_off[j];
   } else {
     const int end = (q0 + mblk < N) ? q0 + mblk : N;
-    for (int k = q0 + 1; k < end; ++k) acc += r[k] * lam_off[k];
+    for (int k = q0 + 1; k < end; ++k) acc += rr(k) * lam_off[k];
   }
   G[(size_t)blockIdx.y * N + j] = acc;
 }
@@ -1415,7 +1419,7 @@ int posterior_async(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fM
   form_shifted_kernel<<<N, 256, 0, s>>>(d_Sigma_inv, N, mblk, d_lam_diag, d_lam_off, 0.0, H, nullptr);
   PPBO_LAUNCH_CHECK(ctx);
   if (int rc = ppbo_potrf_async(ctx, H, N, N, d_info, s)) return rc;
-  if (int rc2 = ppbo_trtri_async(ctx, H, N, N, R, N, s)) return rc2;
+  if (int rc2 = ppbo_trtri_async(ctx, H, N, N, R, N, s, 0, nullptr, d_P ? 1 : 0)) return rc2;   // R^T R reads above the blocks, G = R Lambda does not
   g_build_kernel<<<dim3((N + 255) / 256, N), 256, 0, s>>>(R, N, mblk, d_lam_diag, d_lam_off, d_G);
   PPBO_LAUNCH_CHECK(ctx);
   if (d_P) {

@@ -38,8 +38,10 @@ int ppbo_potrf_fail_bound_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl
 // d_Linv (full N x N, upper part zeroed) = inverse of lower-triangular L
 // skip_top: leave the last doubling level (the split [0, b) | [b, N), b the largest 64 * 2^k < N) unformed and
 // report b in *split_out; the result is then applied with ppbo_apply_linv_async
+// zero_upper = 0: the caller promises never to read above the 64 x 64 diagonal blocks (whose own upper triangles are
+// written as zeros); the 8 N^2-byte memset of the result is skipped
 int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d_Linv, int ldi, hipStream_t s,
-                     int skip_top = 0, int* split_out = nullptr);
+                     int skip_top = 0, int* split_out = nullptr, int zero_upper = 1);
 // d_Ainv (N x N, row pitch N) = Linv^T Linv: lower triangle on the matrix cores, upper triangle mirrored
 int ppbo_syrk_inverse_async(ppbo_ctx* ctx, const double* d_Linv, int N, double* d_Ainv, hipStream_t s);
 int ppbo_apply_linv_async(ppbo_ctx* ctx, const double* d_Linv, int ldi, const double* d_L, int ldl, int N, int split,

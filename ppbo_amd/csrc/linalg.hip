@@ -1057,12 +1057,12 @@ int ppbo_potrf_fail_bound_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl
 }
 
 int ppbo_trtri_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, double* d_Linv, int ldi, hipStream_t s,
-                     int skip_top, int* split_out) {
+                     int skip_top, int* split_out, int zero_upper) {
   if (split_out) *split_out = 0;
   // The full result promises zeros above the diagonal.  With skip_top the caller only ever applies the two
   // diagonal blocks as lower-triangular operators (ppbo_apply_linv_async), nothing above the diagonal blocks
   // is read, and the 33 MB memset per trust-region trial (a blit with its own barriers) is skipped.
-  if (!skip_top) PPBO_HIP_CHECK(ctx, hipMemsetAsync(d_Linv, 0, (size_t)N * ldi * sizeof(double), s));
+  if (!skip_top && zero_upper) PPBO_HIP_CHECK(ctx, hipMemsetAsync(d_Linv, 0, (size_t)N * ldi * sizeof(double), s));
   const int nblk = (N + NB - 1) / NB;
   trtri_diag_kernel<<<nblk, 256, 0, s>>>(d_L, ldl, N, d_Linv, ldi);
   PPBO_LAUNCH_CHECK(ctx);
