@@ -1406,6 +1406,16 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
 
 // Lambda_MAP, alpha, B = Sigma^-1 - Lambda = L_B L_B^T, R = L_B^-1, G = R Lambda (and P = R^T R) -- everything enqueued,
 // the factorization's info word left on the device (d_info)
+// the two info words of a fit into the ctx's host-mapped result record (as doubles), flag last: the host polls the flag
+// instead of paying a device-to-host copy and a stream synchronisation for eight bytes
+__global__ void publish_info_kernel(const int* __restrict__ info, int n, double* __restrict__ rec,
+                                    unsigned long long* __restrict__ flag, unsigned long long epoch) {
+  rec[0] = (double)info[0];
+  rec[1] = n > 1 ? (double)info[1] : 0.0;
+  __threadfence_system();
+  __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int posterior_async(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fMAP, int N, int m, double sigma,
                     double* d_alpha, double* d_lam_diag, double* d_lam_off, double* d_G, double* d_P, int* d_info,
                     hipStream_t s) {
@@ -1520,12 +1530,13 @@ int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, c
       (void)hipStreamSynchronize(s);
       return rc2;
     }
-  int* h2 = (int*)ppbo_pinned(ctx, 64 * sizeof(double) + 64);
-  if (!h2) return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "pinned staging");
-  h2 += 2 * 64;                                  // beyond the fit's 64 doubles
-  h2[0] = h2[1] = 0;
-  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(h2, d_info, (d_G ? 2 : 1) * sizeof(int), hipMemcpyDeviceToHost, s));
-  PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  // the call's ONE host wait: the last launch of the stream publishes the two info words through the host-mapped record
+  PpboHostRecord hr;
+  if (int rc3 = ppbo_host_record(ctx, &hr)) return rc3;
+  publish_info_kernel<<<1, 1, 0, s>>>(d_info, d_G ? 2 : 1, hr.d_rec, hr.d_flag, hr.epoch);
+  PPBO_LAUNCH_CHECK(ctx);
+  if (int rc3 = ppbo_host_record_wait(ctx, hr, s)) return rc3;
+  const int h2[2] = {(int)hr.h_rec[0], (int)hr.h_rec[1]};
   side_guard.side = nullptr;                      // s has waited for the second stream's event: everything is done
   if (h2[0] != 0) {
     if (h_info) *h_info = 1;
