@@ -205,7 +205,11 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
  * ppbo_posterior behind one entry, with what that allows:
  *   - the start is whitened with the factor's inverse that is at hand anyway (z0 = L^-1 f_init: one triangular product);
  *   - no host wait between the phases: the two factorizations' info words and the search's state are read once, at
- *     the end (the search itself is steered through a host-mapped progress word, not through stream synchronisation).
+ *     the end (the search itself is steered through a host-mapped progress word, not through stream synchronisation);
+ *   - with start_is_whitened and N >= 1024 the triangular inverse and Sigma^-1 -- which the search does not need until
+ *     its |grad_f T| rule is armed -- are formed on a second stream owned by the ctx beside the first evaluations; the
+ *     search's stream joins it at a fixed slot, so the result is bitwise that of the one-stream form, and everything
+ *     (both streams) is complete when the call returns.
  * Outputs (device, caller-owned): d_Sigma [N,N] (NULL to skip), d_Sigma_inv [N,N], d_L [N,N] (Cholesky factor of
  * Sigma, lower triangle valid), d_Linv [N,N] (NULL: kept in a workspace), d_fMAP [N], and -- all four or none --
  * d_alpha, d_lam_diag, d_lam_off [N], d_G [N,N] as ppbo_posterior defines them.
