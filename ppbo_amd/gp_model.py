@@ -666,15 +666,33 @@ class GPModel:
         work = torch.empty((M + N + 1, D), dtype=torch.float64, device=self.eng.device)
         work[M:M + N].copy_(self._dX)                                  # the design points themselves
         work[M + N].copy_(self.eng.dev(self.xstar if self.xstar is not None else self.X[0]))
-        # all trials are queued behind each other (the stream orders the re-use of `work`) and read back together: one
-        # synchronisation for the searches, one for the gradient check of the winners
+        # The trials are independent, and after its scoring pass a trial is a latency-bound chain (one workgroup picks
+        # the starts, ASCENT_STARTS workgroups climb): each trial gets a stream and a ctx of its own (the pairs the
+        # concurrent fits use), so the chains of one run beside the scoring of the next (3 trials at C3: 2.7 -> 2.3 ms; ten
+        # trials at C2: 0.43 -> 0.26 ms per trial).
+        # Everything is read back together: one synchronisation for the searches, one for the winners' gradient check.
+        main = torch.cuda.current_stream(self.eng.device)
+        side = self._side_engines(min(trials - 1, 2)) if trials > 1 else []      # three lanes: more do not add overlap
+        lanes = [(self.eng, main)] + side
         queued = []
         for t in range(trials):
-            self.eng.shift_points(pool, np.random.uniform(0.0, 1.0, D), out=work[:M])
-            # the design points (where f_MAP's maxima sit) and the previous x* join the first trial only: they would
-            # claim the same ASCENT_STARTS basins in every trial and leave the uniform candidates' basins unexplored
-            queued.append(self.eng.mean_search(post, work if t == 0 else work[:M], K=ASCENT_STARTS, sep=5e-2,
-                                               iters=ASCENT_ITERS, tol=1e-9, sync=False))
+            shift = np.random.uniform(0.0, 1.0, D)
+            eng_t, st_t = lanes[t % len(lanes)]
+            if 0 < t < len(lanes):
+                st_t.wait_stream(main)                                 # the pool, the posterior, `work` are ready
+            with torch.cuda.stream(st_t):
+                w_t = work if t == 0 else torch.empty((M, D), dtype=torch.float64, device=self.eng.device)
+                eng_t.shift_points(pool, shift, out=w_t[:M])
+                # the design points (where f_MAP's maxima sit) and the previous x* join the first trial only: they would
+                # claim the same ASCENT_STARTS basins in every trial and leave the uniform candidates' basins unexplored
+                queued.append(eng_t.mean_search(post, w_t, K=ASCENT_STARTS, sep=5e-2, iters=ASCENT_ITERS, tol=1e-9,
+                                                sync=False))
+        for _, st_k in side:
+            main.wait_stream(st_k)
+        for t in range(trials):
+            if t % len(lanes):
+                for r in queued[t]:
+                    r.record_stream(main)                              # produced on the trial's stream, read on this one
         found, winners = [], []
         if queued:
             all_x = torch.stack([q[0] for q in queued]).cpu().numpy()            # [trials, K, D]

@@ -111,7 +111,7 @@ def test_mu_star_per_trial_time_at_c2(golden):
     x = load_golden("c2_x")
     g, gp, st = _fitted(golden, "c2")
     np.random.seed(40)
-    gp.mu_star(mustar_finding_trials=1)        # warm: pool upload, workspaces
+    gp.mu_star(mustar_finding_trials=3)        # warm: pool upload, workspaces, the trials' side contexts
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     trials = 10
