@@ -637,7 +637,8 @@ __device__ __forceinline__ void lbfgs_step(WhState* __restrict__ st, int N, int 
     hs.gz2 = gz2;
     int stop = 0;
     if (shs[1] >= 0.0 && shs[1] < hs.gtol2) { hs.status = 1; stop = 1; }
-    else if (hs.stall >= 3) { hs.status = 2; stop = 1; }
+    else if (hs.stall >= 5) { hs.status = 2; stop = 1; }     // (3 until round 4: C4's stored start then stopped ONE evaluation short
+                                                              // of the |grad_f| rule and paid the finisher's factorization: 4.0 instead of 3.5 ms)
     else if (hs.evals >= hs.max_evals) { hs.status = 5; stop = 1; }
     else if (!(gz2 > 0.0)) { hs.status = isfinite(gz2) ? 1 : 4; stop = 1; }
     hs.need_gf = hs.gf_avail && hs.evals >= hs.gf_from && sqrt(gz2) < hs.gate;

@@ -132,7 +132,7 @@ def fit(name, gtol=1e-4, max_evals=3000, verbose=False):
         if gf2 >= 0 and gf2 < gtol * gtol:
             status = 1
             break
-        if stall >= 3:
+        if stall >= 5:
             status = 2
             break
         if evals >= max_evals:
