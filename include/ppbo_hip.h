@@ -178,7 +178,8 @@ typedef struct ppbo_fit_stats {
   int lbfgs_iterations; /* ppbo_fit_fmap_whitened: accepted quasi-Newton steps of the whitened pre-phase (else 0) */
   int lbfgs_evals;      /* ... its objective/gradient evaluations (each O(N^2): two products with L, one with Sigma^-1) */
   int lbfgs_status;     /* ... how it ended: 1 |grad T| < gtol, 2 rounding floor, 3 line search failed, 4 non-finite
-                         * start, 5 budget spent; -1 when the pre-phase did not run */
+                         * start, 5 budget spent, 6 the factor does not exist (Sigma not positive definite: ppbo_gp_fit
+                         * returns PPBO_ERR_NOT_PD); -1 when the pre-phase did not run */
 } ppbo_fit_stats;
 int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double sigma,
                   const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
@@ -208,8 +209,14 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
  *     the end (the search itself is steered through a host-mapped progress word, not through stream synchronisation);
  *   - with start_is_whitened and N >= 1024 the triangular inverse and Sigma^-1 -- which the search does not need until
  *     its |grad_f T| rule is armed -- are formed on a second stream owned by the ctx beside the first evaluations; the
- *     search's stream joins it at a fixed slot, so the result is bitwise that of the one-stream form, and everything
- *     (both streams) is complete when the call returns.
+ *     search's stream joins it at a fixed slot (PPBO_FIT_GF_FROM, default 8), the first evaluation that may apply the
+ *     |grad_f T| rule.  That slot -- not the stream layout -- is what the result depends on: with start_is_whitened and
+ *     N >= 1024 the rule is armed from the same evaluation in the one-stream form (PPBO_FIT_OVERLAP=0) too, so the two
+ *     forms agree bit for bit for every start; without start_is_whitened, or below N = 1024, the rule is armed from
+ *     the first evaluation.  Everything (both streams) is complete when the call returns.
+ *   - a Sigma that is not positive definite ends the search before its first evaluation (the factorization's info word
+ *     is read on the device by the search's first launch): the call returns at once, nothing runs on the half-factored
+ *     matrix.
  * Outputs (device, caller-owned): d_Sigma [N,N] (NULL to skip), d_Sigma_inv [N,N], d_L [N,N] (Cholesky factor of
  * Sigma, lower triangle valid), d_Linv [N,N] (NULL: kept in a workspace), d_fMAP [N], and -- all four or none --
  * d_alpha, d_lam_diag, d_lam_off [N], d_G [N,N] as ppbo_posterior defines them.

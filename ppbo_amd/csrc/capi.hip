@@ -75,13 +75,14 @@ int ppbo_host_record(ppbo_ctx* ctx, PpboHostRecord* out) {
 
 int ppbo_host_record_wait(ppbo_ctx* ctx, const PpboHostRecord& r, hipStream_t s) {
   const volatile unsigned long long* flag = reinterpret_cast<const volatile unsigned long long*>(ctx->hostrec + 2);
-  // the kernels in front of the publishing one take 0.5 ... 5 ms; poll for a bounded time, then let the runtime wait
-  const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned spins = 0;; ++spins) {
-    if (*flag == r.epoch) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return 0; }
-    __builtin_ia32_pause();
-    if ((spins & 0xfff) == 0xfff &&
-        std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+  // the kernels in front of the publishing one take 0.5 ... 5 ms; poll for a bounded time (yielding the core once the
+  // flag has been still for a while), then let the runtime wait
+  PpboSpinWait spin;
+  spin.limit_s = 2.0;
+  for (;;) {
+    const unsigned long long f = *flag;
+    if (f == r.epoch) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return 0; }
+    if (spin.idle(f)) break;
   }
   PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
   if (*flag == r.epoch) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return 0; }
@@ -128,6 +129,7 @@ int ppbo_ctx_create(int device, ppbo_ctx** out) {
   c->syrk_cfg = env_int("PPBO_SYRK_CFG", 0);
   c->fit_overlap = env_int("PPBO_FIT_OVERLAP", 1);
   c->fit_gf_from = env_int("PPBO_FIT_GF_FROM", 8);
+  c->poll_limit_ms = env_int("PPBO_POLL_LIMIT_MS", 5000);
   c->potrf_gen = env_int("PPBO_POTRF_GEN", 3);
   c->rff_nt = env_int("PPBO_RFF_NT", 0);
   c->gram_variant = env_int("PPBO_GRAM_VARIANT", -1);

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -41,6 +44,9 @@ struct ppbo_ctx {
   // search, which needs only L until the |grad_f| rule is armed (fit.hip)
   int fit_overlap = 1;    // PPBO_FIT_OVERLAP
   int fit_gf_from = 8;    // PPBO_FIT_GF_FROM: the first evaluation that may apply the |grad_f| rule in that mode
+  // the host-polled searches let the runtime wait (hipStreamSynchronize) when their progress word has been still for
+  // this long, and carry on if that advanced the search (PPBO_POLL_LIMIT_MS; tests set it to 0 to walk that path)
+  int poll_limit_ms = 5000;
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int syrk_cfg = 0;       // PPBO_SYRK_CFG: tile configuration of Sigma^-1 = Linv^T Linv (0 = by size; 1 / 2 / 3 = 128 / 64 / 32)
@@ -51,6 +57,27 @@ struct ppbo_ctx {
   double* hostrec = nullptr;         // host address
   double* hostrec_dev = nullptr;     // the same memory as the device sees it
   unsigned long long hostrec_epoch = 0;
+};
+
+// Waiting on a host-mapped word without burning a core: spin with `pause` while the word keeps changing (a search
+// slot is 5-50 us), yield the core once it has been still for a while (other contexts' threads -- evidence_batch runs
+// eight -- and the Python interpreter get it), and report after `limit_s` seconds without a change.
+struct PpboSpinWait {
+  unsigned long long last = ~0ull;
+  unsigned still = 0;
+  std::chrono::steady_clock::time_point t_last = std::chrono::steady_clock::now();
+  double limit_s = 5.0;
+  void reset() { still = 0; t_last = std::chrono::steady_clock::now(); }
+  // true: the word has not changed for limit_s seconds
+  bool idle(unsigned long long w) {
+    if (w != last) { last = w; reset(); return false; }
+    ++still;
+    if (still < 2048) { __builtin_ia32_pause(); return false; }
+    sched_yield();
+    if ((still & 0xff) == 0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count() > limit_s) return true;
+    return false;
+  }
 };
 
 struct PpboHostRecord {

@@ -326,7 +326,8 @@ constexpr int LB_MAX_BACKTRACK = 12;
 
 struct WhState {
   int status;      // 0 running, 1 converged (|grad_f| < gtol), 2 stagnated at the rounding floor, 3 line search
-                   // failed along steepest descent, 4 non-finite objective at the start, 5 evaluation budget spent
+                   // failed along steepest descent, 4 non-finite objective at the start, 5 evaluation budget spent,
+                   // 6 the factor L does not exist (its factorization's info word was non-zero)
   int evals, iters, hist, head, first, ls, stall, need_gf, max_evals;
   int gf_avail;    // 0: Sigma^-1 f is not available to the judgement (|grad_f| cannot be asked for); always 1 today
   int gf_from;     // the |grad_f| rule is armed from this evaluation on (ppbo_gp_fit with the side stream: Sigma^-1 is
@@ -347,26 +348,6 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const double* __restric
   for (int k = lane; k <= i; k += 64) s += row[k] * row[k];
   s = wave_sum(s);
   if (lane == 0) rowsq[i] = s;
-}
-
-__global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ st, const double* __restrict__ rowsq,
-                                                          int N, double gtol, int max_evals, int gf_avail, int gf_from) {
-  __shared__ double sh[LB_T / 64];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < N; i += LB_T) s += rowsq[i];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int w = 0; w < LB_T / 64; ++w) t += sh[w];
-    st->status = 0; st->evals = 0; st->iters = 0; st->hist = 0; st->head = 0; st->first = 1; st->ls = 0;
-    st->stall = 0; st->need_gf = 0; st->max_evals = max_evals; st->gf_avail = gf_avail; st->gf_from = gf_from;
-    st->phi = 0.0; st->dphi = 0.0; st->alpha = 0.0; st->gz2 = 0.0; st->gf2 = -1.0;
-    st->gate = gtol * sqrt(t);          // |grad_f| < gtol needs |grad_z| < gtol |L|_F
-    st->gtol2 = gtol * gtol;
-    st->gzbest = INFINITY;
-  }
 }
 
 // K sums over the NT threads of the workgroup, each thread holding K partials.  Quad sums by DPP (VALU only), one
@@ -429,6 +410,36 @@ __device__ __forceinline__ void wh_publish(const WhProgress& pr, const WhHead& h
                      __HIP_MEMORY_SCOPE_SYSTEM);
 }
 static_assert(sizeof(WhHead) == offsetof(WhState, B), "WhHead mirrors the head of WhState");
+
+__global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ st, const double* __restrict__ rowsq,
+                                                          int N, double gtol, int max_evals, int gf_avail, int gf_from,
+                                                          const int* __restrict__ factor_info, WhProgress prog) {
+  __shared__ double sh[LB_T / 64];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < N; i += LB_T) s += rowsq[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < LB_T / 64; ++w) t += sh[w];
+    st->status = 0; st->evals = 0; st->iters = 0; st->hist = 0; st->head = 0; st->first = 1; st->ls = 0;
+    st->stall = 0; st->need_gf = 0; st->max_evals = max_evals; st->gf_avail = gf_avail; st->gf_from = gf_from;
+    st->phi = 0.0; st->dphi = 0.0; st->alpha = 0.0; st->gz2 = 0.0; st->gf2 = -1.0;
+    st->gate = gtol * sqrt(t);          // |grad_f| < gtol needs |grad_z| < gtol |L|_F
+    st->gtol2 = gtol * gtol;
+    st->gzbest = INFINITY;
+    // the factor the search walks on does not exist (potrf stopped at a non-positive pivot and left its info word on
+    // the device): end the search before its first slot, so that the host hears of it at once instead of running the
+    // whole pipeline on a half-factored matrix
+    if (factor_info && factor_info[0] != 0) {
+      st->status = 6;
+      WhHead hs = *reinterpret_cast<const WhHead*>(st);
+      wh_publish(prog, hs);
+    }
+  }
+}
+
 
 // One judgement of the trial point zt (its products u = L^T beta(L zt), v = Sigma^-1 L zt and the per-query
 // likelihood sums tq are already in memory).  tests/probes/whitened_lbfgs_proto.py is the NumPy statement of the
@@ -1223,6 +1234,7 @@ constexpr int WH_AHEAD = 3;
 struct WhitenedExtras {
   const double* d_Linv = nullptr;    // when given: z0 = L^-1 f_init by one triangular product (else L^T (Sigma^-1 f_init))
   bool start_is_z = false;           // d_f_init IS z0
+  const int* d_factor_info = nullptr; // the device info word of the factorization that produced d_L (ahead on the same stream)
   bool sync_at_end = true;           // false: d_fMAP is only enqueued (the caller synchronises later)
   hipEvent_t join_event = nullptr;   // when given: Sigma^-1 (and L^-1) are being produced on another stream; the search's
   int gf_from = 0;                   // stream waits for this event before slot gf_from, the first that may read them
@@ -1260,7 +1272,7 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
   *h_word = 0;                          // nothing of this ctx is in flight that could write it (one search per ctx at a time)
   PPBO_HIP_CHECK(ctx, hipMemsetAsync(base, 0, (st_doubles + (size_t)LB_NB * N) * sizeof(double), s));
   row_sqnorm_kernel<<<(N + 3) / 4, 256, 0, s>>>(d_L, N, ldl, rowsq);
-  lbfgs_init_kernel<<<1, LB_T, 0, s>>>(st, rowsq, N, gtol, max_evals, 1, ex.join_event ? ex.gf_from : 0);
+  lbfgs_init_kernel<<<1, LB_T, 0, s>>>(st, rowsq, N, gtol, max_evals, 1, ex.gf_from, ex.d_factor_info, prog);
   PPBO_LAUNCH_CHECK(ctx);
   if (ex.start_is_z) {
     PPBO_HIP_CHECK(ctx, hipMemcpyAsync(zt, d_f_init, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1317,10 +1329,10 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
     return 0;
   };
   int enq = 0, status = 0, evals = 0;
-  bool synced = false, joined = false;
-  auto t_last = std::chrono::steady_clock::now();
-  unsigned long long last_word = 0;
-  for (unsigned spins = 0;; ++spins) {
+  bool stalled = false, joined = false;
+  PpboSpinWait spin;
+  spin.limit_s = 1e-3 * ctx->poll_limit_ms;
+  for (;;) {
     const unsigned long long w = *h_word;
     status = (int)(w >> 32);
     evals = (int)(w & 0xffffffffu);
@@ -1334,24 +1346,36 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
       ++enq;
       continue;
     }
-    __builtin_ia32_pause();
-    if (w != last_word) { last_word = w; t_last = std::chrono::steady_clock::now(); }
-    else if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t_last > std::chrono::seconds(5)) {
-      // no progress word for seconds: let the runtime wait and read the state the ordinary way
-      PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
-      synced = true;
-      break;
-    }
+    if (!spin.idle(w)) continue;
+    // no progress word for seconds (work queued in front of this call, ranks sharing the GPU, a profiler serialising
+    // the stream ...): let the runtime wait for what is enqueued.  Afterwards every enqueued slot has run, so either the
+    // search has ended, or it has advanced -- then it just needs more slots -- or the slots really do nothing.
+    PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    const unsigned long long w2 = *h_word;
+    if ((int)(w2 >> 32) != 0 || (int)(w2 & 0xffffffffu) > evals) { spin.reset(); continue; }
+    stalled = true;
+    break;
   }
   PPBO_LAUNCH_CHECK(ctx);
   if (ex.join_event && !joined) PPBO_HIP_CHECK(ctx, hipStreamWaitEvent(s, ex.join_event, 0));   // the finisher, alpha, the posterior need them
+  // (gated dead slots may still be queued behind the one that ended the search; they read the search's state in the
+  // ctx's workspaces.  Every way out of here waits for the stream -- the standalone entry synchronises, ppbo_gp_fit's one
+  // host wait is on a launch behind them -- so nothing of this search is in flight when the entry returns.)
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   WhHead head;
-  if (synced && (int)(*h_word >> 32) == 0) {
+  if (stalled) {
+    // a full synchronisation brought no new evaluation: read the state the ordinary way (the host-mapped word may be
+    // the thing that is broken)
     PPBO_HIP_CHECK(ctx, hipMemcpy(&head, st, sizeof(WhHead), hipMemcpyDeviceToHost));
-    if (head.status == 0) return ppbo_set_error(ctx, (int)hipErrorUnknown, "the whitened search made no progress");
+    if (head.status == 0)
+      return ppbo_set_error(ctx, (int)hipErrorUnknown, "the whitened search made no progress (%d slots enqueued, %d evaluations)",
+                            enq, head.evals);
   } else {
     std::memcpy(&head, h_head, sizeof(WhHead));
+  }
+  if (head.status == 6) {
+    (void)hipStreamSynchronize(s);
+    return ppbo_set_error(ctx, PPBO_ERR_NOT_PD, "the factor handed to the whitened search does not exist: its matrix is not positive definite");
   }
   if (verbose)
     printf("[ppbo_fit whitened] evals %d iters %d phi %.12e |grad_z| %.3e |grad_f| %.3e status %d (slots enqueued %d)\n",
@@ -1476,7 +1500,11 @@ int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, c
   double* Li = d_Linv ? d_Linv : W + nn;     // the posterior reuses this half for R -- after the GEMM below has read it
   // Sigma (kept for the caller) and the matrix the factorization overwrites: the Gram kernel runs twice (8.6 us at
   // N = 2048) instead of once plus a 33 MB device-to-device copy (12 us)
-  const bool overlap = ctx->fit_overlap && opts && opts->start_is_whitened != 0 && N >= 1024;
+  // With a whitened start at N >= 1024 the |grad_f T| rule of the search is armed from evaluation fit_gf_from on -- in
+  // the two-stream form because Sigma^-1 is not there before, in the one-stream form (PPBO_FIT_OVERLAP=0) so that both
+  // give the same answer bit for bit: the result depends on the inputs, not on how the launches were laid out.
+  const bool gf_deferred = opts && opts->start_is_whitened != 0 && N >= 1024;
+  const bool overlap = ctx->fit_overlap && gf_deferred;
   hipStream_t s2 = s;
   // an error return after the fork must not leave the second stream working on buffers the caller may free
   struct SideGuard {
@@ -1516,15 +1544,25 @@ int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, c
   if (overlap) {
     PPBO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, s2));
     ex.join_event = ctx->ev_join;
-    ex.gf_from = ctx->fit_gf_from;
   }
+  if (gf_deferred) ex.gf_from = ctx->fit_gf_from;
+  ex.d_factor_info = d_info;
   ex.d_Linv = Li;
   ex.start_is_z = opts && opts->start_is_whitened != 0;
   ex.sync_at_end = false;
   ppbo_fit_stats stt{};
   int rc = whitened_search(ctx, d_L, N, d_Sigma_inv, N, m, theta[0], d_f_init, opts, d_fMAP, &stt, s, ex);
   if (h_stats) *h_stats = stt;
-  if (rc) { (void)hipStreamSynchronize(s); return rc; }
+  if (rc) {
+    (void)hipStreamSynchronize(s);
+    // whatever the search or its finisher made of it: a Sigma that is not positive definite is THE error of this call
+    int info0 = 0;
+    if (hipMemcpy(&info0, d_info, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && info0 != 0) {
+      if (h_info) *h_info = 1;
+      return ppbo_set_error(ctx, PPBO_ERR_NOT_PD, "Sigma is not positive definite (leading minor %d)", info0);
+    }
+    return rc;
+  }
   if (d_G)
     if (int rc2 = posterior_async(ctx, d_Sigma_inv, d_fMAP, N, m, theta[0], d_alpha, d_lam_diag, d_lam_off, d_G, nullptr,
                                   d_info + 1, s)) {

@@ -823,34 +823,40 @@ int ppbo_rff_omega_map(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, 
     else om_step_kernel<0><<<1, 1024, 0, s>>>(st, buf, F, tq, n_q, m, d_omega, prog);
   };
   constexpr int OM_AHEAD = 4;
-  int enq = 0, status = 0;
-  bool synced = false;
-  auto t_last = std::chrono::steady_clock::now();
-  unsigned long long last_word = 0;
-  for (unsigned spins = 0;; ++spins) {
+  int enq = 0, status = 0, done = 0;
+  bool stalled = false;
+  PpboSpinWait spin;
+  spin.limit_s = 1e-3 * ctx->poll_limit_ms;
+  for (;;) {
     const unsigned long long w = *h_word;
     status = (int)(w >> 32);
     if (status != 0) break;
-    const int done = (int)(w & 0xffffffffu);      // slot k's step kernel reports it = k + 1 (slot 0 evaluates the start point)
+    done = (int)(w & 0xffffffffu);                // slot k's step kernel reports it = k + 1 (slot 0 evaluates the start point)
     if (enq - done < OM_AHEAD && enq < maxiter + 2) {
       enqueue_slot();
       ++enq;
       continue;
     }
-    __builtin_ia32_pause();
-    if (w != last_word) { last_word = w; t_last = std::chrono::steady_clock::now(); }
-    else if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t_last > std::chrono::seconds(5)) {
-      PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));      // no progress word for seconds: read the state the ordinary way
-      synced = true;
-      break;
-    }
+    if (!spin.idle(w)) continue;
+    // no progress word for seconds: let the runtime wait for what is enqueued; if that advanced the search it simply
+    // needs more slots (a slow or shared device is not an error)
+    PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    const unsigned long long w2 = *h_word;
+    if ((int)(w2 >> 32) != 0 || (int)(w2 & 0xffffffffu) > done) { spin.reset(); continue; }
+    stalled = true;
+    break;
   }
   PPBO_LAUNCH_CHECK(ctx);
+  // gated dead slots still queued behind the one that ended the search read `st` and the vectors in the ctx's workspaces:
+  // nothing of this search may be in flight when the entry returns (the next call may come in on another stream, or
+  // with another F, which moves `st`)
+  if (enq > done) PPBO_HIP_CHECK(ctx, hipStreamSynchronize(s));
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   OmHead head;
-  if (synced && (int)(*h_word >> 32) == 0) {
+  if (stalled) {
     PPBO_HIP_CHECK(ctx, hipMemcpy(&head, st, sizeof(OmHead), hipMemcpyDeviceToHost));
-    if (head.status == 0) return ppbo_set_error(ctx, (int)hipErrorUnknown, "the omega_MAP search made no progress");
+    if (head.status == 0)
+      return ppbo_set_error(ctx, (int)hipErrorUnknown, "the omega_MAP search made no progress (%d slots enqueued)", enq);
   } else {
     std::memcpy(&head, h_head, sizeof(OmHead));
   }

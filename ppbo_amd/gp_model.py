@@ -532,7 +532,16 @@ class GPModel:
                                  n_cholesky=st["n_cholesky"], lbfgs_evals=st["lbfgs_evals"],
                                  lbfgs_status=st["lbfgs_status"], converged=st["converged"], warm=False,
                                  seconds=time.time() - start))
-        self.fMAP = r["fMAP"].cpu().numpy()
+        fm_host = r["fMAP"].cpu().numpy()
+        if not (np.isfinite(st["T"]) and st["lbfgs_status"] != 4 and np.all(np.isfinite(fm_host))):
+            # the start had no finite objective and the finisher did not recover one: what update_fMAP does when every
+            # trial ends that way -- the previous estimate (and the previous posterior) stay
+            print("---!!!--- f_MAP search produced no finite objective; keeping the previous f_MAP ---!!!---")
+            if self.fMAP is None or len(self.fMAP) != self.N:
+                self.fMAP = np.zeros(self.N)
+            self._refresh_mean_state(self.eng.dev(self.fMAP))
+            return True
+        self.fMAP = fm_host
         if self.verbose:
             print("... this took " + str(time.time() - start) + " seconds.")
             print("Current theta is: " + str(self.theta) + " (Acq. = " + str(self.xi_acquisition_function) + ")")

@@ -129,3 +129,83 @@ def test_gp_fit_reports_a_posterior_that_is_not_positive_definite(eng, golden):
         eng.gp_fit(X, g["theta"], kern, m, np.zeros(X.shape[0] + 1))
     with pytest.raises(RuntimeError):
         eng.gp_fit(X, [0.0, 0.3, 0.5], kern, m, g["f_init"])          # sigma must be positive
+
+
+@pytest.mark.parametrize("name,whitened", [("smoke", False), ("smoke", True), ("c3", False), ("c3", True)])
+def test_gp_fit_says_so_at_once_when_sigma_is_not_positive_definite(eng, golden, name, whitened):
+    """A negative shrinkage pushes Sigma's small eigenvalues below zero: potrf stops early and leaves a half-factored
+    matrix.  The search's first launch reads the info word on the device and ends the search before its first
+    evaluation, so the call returns PPBO_ERR_NOT_PD with info = 1 -- not whatever the pipeline would have made of the
+    garbage -- and the ctx is as good as new afterwards."""
+    from ppbo_amd.engine import NotPositiveDefinite
+    g = golden(name)
+    X, th, kern, m = g["X"], g["theta"], str(g["kernel"]), int(g["m"])
+    z0 = np.random.default_rng(3).standard_normal(X.shape[0])
+    start = z0 if whitened else g["f_init"]
+    good = eng.gp_fit(X, th, kern, m, start, start_is_whitened=whitened)
+    with pytest.raises(NotPositiveDefinite) as e:
+        eng.gp_fit(X, th, kern, m, start, shrink=-0.5, start_is_whitened=whitened)
+    assert e.value.info == 1 and "Sigma is not positive definite" in str(e.value)
+    again = eng.gp_fit(X, th, kern, m, start, start_is_whitened=whitened)
+    assert again["stats"] == good["stats"] and np.array_equal(host(again["fMAP"]), host(good["fMAP"]))
+
+
+def test_whitened_search_stops_on_a_missing_factor(eng, golden):
+    """The standalone entry cannot see a factorization's info word (it is handed L); ppbo_gp_fit hands it over, and
+    status 6 is what the search reports then: zero evaluations."""
+    g = golden("smoke")
+    X, th, kern, m = g["X"], g["theta"], str(g["kernel"]), int(g["m"])
+    from ppbo_amd.engine import NotPositiveDefinite
+    with pytest.raises(NotPositiveDefinite):
+        eng.gp_fit(X, th, kern, m, g["f_init"], shrink=-0.5, want_posterior=False, want_Sigma=False)
+
+
+def test_gp_model_raises_not_positive_definite_through_the_fused_fit(eng, golden):
+    from ppbo_amd.engine import NotPositiveDefinite
+    from test_gpu_dropin import _model
+    g = golden("smoke")
+    model, _ = _model(g)
+    model.COVARIANCE_SHRINKAGE = -0.5
+    np.random.seed(0)
+    with pytest.raises(NotPositiveDefinite):
+        model.update_model()
+
+
+@pytest.mark.parametrize("name", ["c2", "c3"])
+def test_a_stalled_progress_word_is_not_an_error(golden, monkeypatch, name):
+    """PPBO_POLL_LIMIT_MS = 0: every time the host has nothing to enqueue and the progress word has been still for
+    ~2000 polls it falls back to hipStreamSynchronize -- the path a slow or shared device takes after five seconds.
+    The search must carry on from there with more slots (it used to report 'made no progress') and end
+    exactly where the undisturbed one does."""
+    from ppbo_amd.engine import Engine, get_engine
+    g = golden(name)
+    X, th, kern, m = g["X"], g["theta"], str(g["kernel"]), int(g["m"])
+    ref = get_engine(0).gp_fit(X, th, kern, m, g["f_init"])
+    monkeypatch.setenv("PPBO_POLL_LIMIT_MS", "0")
+    slow = Engine(0)
+    try:
+        r = slow.gp_fit(X, th, kern, m, g["f_init"])
+        assert r["stats"] == ref["stats"] and np.array_equal(host(r["fMAP"]), host(ref["fMAP"]))
+        f, st = slow.fit_fmap(r["Sigma_inv"], g["f_init"], m, float(th[0]), L=r["L"])
+        f2, st2 = get_engine(0).fit_fmap(ref["Sigma_inv"], g["f_init"], m, float(th[0]), L=ref["L"])
+        assert st == st2 and np.array_equal(host(f), host(f2))
+    finally:
+        slow.close()
+
+
+def test_a_stalled_progress_word_is_not_an_error_for_omega_map(monkeypatch):
+    """The same for ppbo_rff_omega_map (several hundred slots): same iterate count, same point, bit for bit."""
+    from ppbo_amd.engine import Engine, get_engine
+    rng = np.random.default_rng(2)
+    m, n_q, F = 5, 9, 1500
+    N = n_q * (m + 1)
+    Phi = rng.standard_normal((F, N)) * 0.2 * np.sqrt(70.0 / F)
+    w0 = rng.standard_normal(F)
+    om, S, gn, it = get_engine(0).rff_omega_map(Phi, w0, m, 0.3, maxiter=500, gtol=1e-6)
+    monkeypatch.setenv("PPBO_POLL_LIMIT_MS", "0")
+    slow = Engine(0)
+    try:
+        om2, S2, gn2, it2 = slow.rff_omega_map(Phi, w0, m, 0.3, maxiter=500, gtol=1e-6)
+        assert it2 == it and S2 == S and gn2 == gn and np.array_equal(om2, om)
+    finally:
+        slow.close()
