@@ -193,19 +193,25 @@ template <class C, int MINW, bool ALWAYS_FAST>
 __global__ __launch_bounds__(C::NT, MINW) void quadform_kernel(const double* __restrict__ G, int N,
                                                                const double* __restrict__ Kt, int ldk, int M,
                                                                int tri_block, double* __restrict__ slab, int ntm,
-                                                               int ntn, int swizzle) {
+                                                               int ntn, int swizzle, int n_rows) {
   int id = blockIdx.x;
-  if (swizzle & 1) {                   // XCD-aware: consecutive logical ids share an XCD / L2
-    const int per = gridDim.x >> 3;
-    id = (id & 7) * per + (id >> 3);
+  if (swizzle & 1) {                   // XCD-aware: consecutive logical ids share an XCD / L2 (workgroup b runs on XCD b % 8)
+    const int per = gridDim.x >> 3, rem = gridDim.x & 7;
+    const int xcd = id & 7, pos = id >> 3;            // a bijection for any grid size: XCDs [0, rem) hold per + 1 ids
+    id = pos + (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per);
   }
   int mt, nt;
   if (swizzle & 2) {                   // candidate tile fastest: co-resident workgroups share one G row panel
     const int ch = swizzle >> 2;       // optional: candidate tiles in chunks of ch (K* chunk stays in the Infinity Cache)
-    if (ch > 0 && ntn % ch == 0) {
-      const int per_chunk = ntm * ch;
-      const int c = id / per_chunk, rem = id % per_chunk;
-      mt = ntm - 1 - (rem / ch); nt = c * ch + (rem % ch);
+    if (ch > 0 && ch < ntn) {
+      const int per_chunk = ntm * ch, full = ntn / ch;
+      if (id < full * per_chunk) {
+        const int c = id / per_chunk, r = id % per_chunk;
+        mt = ntm - 1 - (r / ch); nt = c * ch + (r % ch);
+      } else {                         // the last, narrower chunk
+        const int cw = ntn - full * ch, r = id - full * per_chunk;
+        mt = ntm - 1 - (r / cw); nt = full * ch + (r % cw);
+      }
     } else {
       mt = ntm - 1 - (id / ntn); nt = id % ntn;
     }
@@ -213,13 +219,18 @@ __global__ __launch_bounds__(C::NT, MINW) void quadform_kernel(const double* __r
     mt = ntm - 1 - (id % ntm); nt = id / ntm;
   }
   const int m0 = mt * C::BM, n0 = nt * C::BN;
-  const int e = ((m0 + C::BM + tri_block - 1) / tri_block) * tri_block;
+  // G is zero right of the last star that reaches into this row tile; the K range ends there, rounded UP to the chunk
+  // depth (g_build_kernel writes the zeros of every row explicitly, so the extra columns multiply zeros): every K
+  // range is then a whole number of chunks whatever the star size -- m = 25, the reference's default, has 26-row stars
+  const int e = (((m0 + C::BM + tri_block - 1) / tri_block) * tri_block + BK - 1) & ~(BK - 1);
   const int kend = e < N ? e : N;
   double4_t acc[C::TM][C::TN];
   zero_acc<C>(acc);
   // rows of this wavefront end at m0 + (wm+1)*TM*16: G is zero beyond the end of their last star block
-  const int wrow_end = m0 + ((int)(threadIdx.x >> 6) / C::WN + 1) * C::TM * 16;
-  const int wk = ((wrow_end + tri_block - 1) / tri_block) * tri_block;
+  const int wrow_beg = m0 + ((int)(threadIdx.x >> 6) / C::WN) * C::TM * 16;
+  const int wrow_end = wrow_beg + C::TM * 16;
+  // (a wavefront whose rows all lie in the zero frame below the real matrix multiplies nothing)
+  const int wk = wrow_beg >= n_rows ? 0 : ((wrow_end + tri_block - 1) / tri_block) * tri_block;
   mainloop<C, KC, RC, ALWAYS_FAST>(G, N, Kt, ldk, N, M, m0, n0, 0, kend, acc, wk < kend ? wk : kend);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / C::WN, wn = wave % C::WN;
@@ -253,21 +264,26 @@ using QF3 = Cfg<4, 4, 2, 2>;   // 16 waves of 32x32, 1 WG/CU -> 4 waves/SIMD
 using QF4 = Cfg<4, 4, 2, 2>;   // same tile, 2 WG/CU -> 8 waves/SIMD (<= 64 VGPRs)
 using QF5 = Cfg<8, 2, 2, 4>;   // 256 x 128 tile, 16 waves of 32x64, 1 WG/CU: K* re-read once per 256 G rows
 
+// G [rows >= ntm BM][N] with row stride N, Kt [N][ldk]: `N` is the K extent AND G's row stride.  The lean (unguarded)
+// loop runs when every tile is in bounds and every K range a whole number of chunks: N % 16 == 0, the row tiles
+// backed by memory (g_rows >= ntm BM) and the candidate tiles too (ldk >= ntn BN; what the columns beyond Mc hold does
+// not matter, each output column depends on its own K* column only and the slab is written for c < Mc).
+// predict_passes pads its operands so that this always holds.
 template <class C, int MINW>
-int launch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, int ldk, int Mc, int mblk,
-                    double* slab, hipStream_t s) {
+int launch_quadform(ppbo_ctx* ctx, const double* G, int N, int g_rows, int n_rows, const double* Kt, int ldk, int Mc,
+                    int mblk, double* slab, hipStream_t s) {
   const size_t lds = C::LDS_DOUBLES * sizeof(double);
   ppbo_lds_limit(ctx, (const void*)quadform_kernel<C, MINW, true>, (int)lds);
   ppbo_lds_limit(ctx, (const void*)quadform_kernel<C, MINW, false>, (int)lds);
-  const int ntm = (N + C::BM - 1) / C::BM, ntn = (Mc + C::BN - 1) / C::BN;
+  const int ntm = (g_rows + C::BM - 1) / C::BM, ntn = (Mc + C::BN - 1) / C::BN;
   const int grid = ntm * ntn;
   const int order = ctx->qf_order;   // PPBO_QF_ORDER; default 514 = candidate-tile fastest in chunks of 128 tiles (measured best: profiles/r04_quadform_traffic_vs_order.txt)
-  const int swz = ((grid % 8 == 0 && grid >= 64) ? (order & 1) : 0) | (order & ~1);
+  const int swz = (grid >= 64 ? (order & 1) : 0) | (order & ~1);
   // every tile in bounds, 16-byte aligned, and every K range a multiple of 16?
-  const bool fast = (N % C::BM == 0) && (Mc % C::BN == 0) && (N % 2 == 0) && (ldk % 2 == 0) && (mblk % 16 == 0 || mblk == 1 || (C::BM % mblk == 0)) &&
+  const bool fast = (g_rows % C::BM == 0) && (ldk >= ntn * C::BN) && (N % BK == 0) && (ldk % 2 == 0) &&
                     ((reinterpret_cast<uintptr_t>(G) & 15) == 0) && ((reinterpret_cast<uintptr_t>(Kt) & 15) == 0);
-  if (fast) quadform_kernel<C, MINW, true><<<grid, C::NT, lds, s>>>(G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn, swz);
-  else quadform_kernel<C, MINW, false><<<grid, C::NT, lds, s>>>(G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn, swz);
+  if (fast) quadform_kernel<C, MINW, true><<<grid, C::NT, lds, s>>>(G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn, swz, n_rows);
+  else quadform_kernel<C, MINW, false><<<grid, C::NT, lds, s>>>(G, N, Kt, ldk, Mc, mblk, slab, ntm, ntn, swz, n_rows);
   PPBO_LAUNCH_CHECK(ctx);
   return 0;
 }
@@ -275,16 +291,32 @@ int launch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, int
 // ctx->qf_variant (PPBO_QF_VARIANT); default 2 = measured best on MI355X: 8 waves of 32x64, 4 waves/SIMD
 int quadform_variant(const ppbo_ctx* ctx) { return ctx->qf_variant; }
 
-int dispatch_quadform(ppbo_ctx* ctx, const double* G, int N, const double* Kt, int ldk, int Mc, int mblk,
-                      double* slab, hipStream_t s) {
+int dispatch_quadform(ppbo_ctx* ctx, const double* G, int N, int g_rows, int n_rows, const double* Kt, int ldk, int Mc,
+                      int mblk, double* slab, hipStream_t s) {
   switch (quadform_variant(ctx)) {
-    case 1: return launch_quadform<QF1, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
-    case 2: return launch_quadform<QF2, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
-    case 3: return launch_quadform<QF3, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
-    case 4: return launch_quadform<QF4, 8>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
-    case 5: return launch_quadform<QF5, 4>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
-    default: return launch_quadform<QF0, 2>(ctx, G, N, Kt, ldk, Mc, mblk, slab, s);
+    case 1: return launch_quadform<QF1, 4>(ctx, G, N, g_rows, n_rows, Kt, ldk, Mc, mblk, slab, s);
+    case 2: return launch_quadform<QF2, 4>(ctx, G, N, g_rows, n_rows, Kt, ldk, Mc, mblk, slab, s);
+    case 3: return launch_quadform<QF3, 4>(ctx, G, N, g_rows, n_rows, Kt, ldk, Mc, mblk, slab, s);
+    case 4: return launch_quadform<QF4, 8>(ctx, G, N, g_rows, n_rows, Kt, ldk, Mc, mblk, slab, s);
+    case 5: return launch_quadform<QF5, 4>(ctx, G, N, g_rows, n_rows, Kt, ldk, Mc, mblk, slab, s);
+    default: return launch_quadform<QF0, 2>(ctx, G, N, g_rows, n_rows, Kt, ldk, Mc, mblk, slab, s);
   }
+}
+
+// Gp [rows_p][cols_p] = G [N][N] framed with zeros: the operand of the quadratic form when N is not a multiple of its
+// row tile / chunk depth (every tile of the launch is then in bounds and takes the lean loop; 3 N^2 x 8 bytes moved
+// once per call -- 20 us at N = 2080 against the ~1 ms the guarded loop costs per 65536 candidates)
+__global__ __launch_bounds__(256) void pad_square_kernel(const double* __restrict__ G, int N, double* __restrict__ Gp,
+                                                         int rows_p, int cols_p) {
+  const int i = blockIdx.y;
+  const int j = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (j >= cols_p) return;
+  double2 v = {0.0, 0.0};
+  if (i < N) {
+    if (j < N) v.x = G[(size_t)i * N + j];
+    if (j + 1 < N) v.y = G[(size_t)i * N + j + 1];
+  }
+  *reinterpret_cast<double2*>(Gp + (size_t)i * cols_p + j) = v;
 }
 
 // Z = Lambda K*  (star-graph rows), Kt/Z are [N, M] with row stride ld
@@ -742,17 +774,34 @@ static int predict_passes(ppbo_ctx* ctx, const ppbo_model* model, const double* 
   const int64_t n_chunks = (M + chunk_cap - 1) / chunk_cap;
   const int qf_bm = (quadform_variant(ctx) == 5) ? 256 : 128;
   const int ntm = (N + qf_bm - 1) / qf_bm;   // slabs = row tiles of the shipped quadform shape
+  // The quadratic form's operands are PADDED so that every tile of its launch takes the unguarded main loop whatever
+  // N, the star size and the candidate count are (the reference's default m = 25 gives N = 26 n_q: the guarded loop
+  // cost 23 % at N = 2080, profiles/r05_ragged_shapes.txt): K extent Nk = N rounded up to the chunk depth (K* rows
+  // [N, Nk) zeroed), G's rows up to a whole row tile (copied into a zero frame when N itself is not one), K*'s row
+  // stride up to a whole candidate tile (the surplus columns feed only their own, unread, outputs).
+  const int Nk = (N + BK - 1) & ~(BK - 1);
+  const int g_rows = ntm * qf_bm;
+  const bool pad_g = want_var && (g_rows != N || Nk != N || (reinterpret_cast<uintptr_t>(model->d_G) & 15) != 0);
 
   // workspaces sized for the largest chunk
   const int Mc_max = (int)(M < chunk_cap ? M : chunk_cap);
-  const int ldk = (Mc_max + 1) & ~1;
+  const int ldk = (Mc_max + 127) & ~127;
   const int n_split = pick_split(Mc_max, n_q);
   const int q_per_split = (n_q + n_split - 1) / n_split;
   const int n_split_eff = (n_q + q_per_split - 1) / q_per_split;
   double* Kt = nullptr;
   if (want_var) {
-    Kt = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_KSTAR, (size_t)N * ldk * sizeof(double));
+    Kt = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_KSTAR, (size_t)Nk * ldk * sizeof(double));
     if (!Kt) return (int)hipErrorOutOfMemory;
+    if (Nk != N) PPBO_HIP_CHECK(ctx, hipMemsetAsync(Kt + (size_t)N * ldk, 0, (size_t)(Nk - N) * ldk * sizeof(double), s));
+  }
+  const double* Gq = model->d_G;
+  if (pad_g) {
+    double* Gp = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_GPAD, (size_t)g_rows * Nk * sizeof(double));
+    if (!Gp) return (int)hipErrorOutOfMemory;
+    pad_square_kernel<<<dim3((Nk / 2 + 255) / 256, g_rows), 256, 0, s>>>(model->d_G, N, Gp, g_rows, Nk);
+    PPBO_LAUNCH_CHECK(ctx);
+    Gq = Gp;
   }
   const size_t part_doubles = (size_t)(2 * n_split_eff + ntm) * Mc_max;
   double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_PART, part_doubles * sizeof(double));
@@ -775,7 +824,7 @@ static int predict_passes(ppbo_ctx* ctx, const ppbo_model* model, const double* 
     PPBO_LAUNCH_CHECK(ctx);
     if (want_var) {
       PpboProfScope pf(ctx, ppbo_ctx::PF_QUADFORM, s);
-      if (int rc = dispatch_quadform(ctx, model->d_G, N, Kt, ldk, Mc, mblk, slab, s)) return rc;
+      if (int rc = dispatch_quadform(ctx, Gq, pad_g ? Nk : N, pad_g ? g_rows : N, N, Kt, ldk, Mc, mblk, slab, s)) return rc;
     }
     const int sblocks = score_blocks(Mc);
     PpboProfScope pfs(ctx, ppbo_ctx::PF_SCORE, s);

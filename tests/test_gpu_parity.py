@@ -751,6 +751,42 @@ def test_variance_contraction_fast_path_star_sizes(eng, m):
     assert np.abs(host(out["var"]) - var0).max() <= 1e-7 * th[2] ** 2
 
 
+@pytest.mark.parametrize("m,n_q,M", [(25, 5, 100), (25, 10, 257), (25, 21, 1000), (9, 13, 129), (2, 43, 128), (30, 9, 640),
+                                     (25, 40, 1111), (40, 7, 300), (12, 20, 4097)])
+def test_variance_contraction_ragged_shapes(eng, m, n_q, M):
+    """Star sizes that divide neither the 16-deep chunk nor the 128-row tile (m = 25 is the reference's default,
+    src/ppbo_settings.py:14: N = 26 n_q), N off every tile edge, candidate counts off the 128-column tile: the
+    quadratic form then runs on a zero-framed copy of G with K* padded to whole tiles (predict_passes) so that every
+    workgroup takes the unguarded loop.  Mean, variance, score and the argmax against the oracle's dense operator."""
+    D = 4
+    th = [0.3, 0.6, 0.8]
+    X = orc.synthetic_design(n_q, D, m=m, seed=100 * m + n_q)
+    N = X.shape[0]
+    assert N == n_q * (m + 1)
+    S0 = orc.gram(X, th, "SE_kernel")
+    Sinv0 = orc.pd_inverse(S0)
+    f_init = np.random.default_rng(m).multivariate_normal(np.zeros(N), S0, method="cholesky")
+    f0, _ = orc.fit_fmap_trust_exact(f_init, Sinv0, m, th[0], gtol=1e-9)
+    post = eng.posterior(X, th, "SE_kernel", eng.pd_inverse(eng.gram(X, th, "SE_kernel")), f0, m)
+    P0 = orc.posterior_covariance(Sinv0, f0, m, th[0])
+    A0 = orc.variance_operator(Sinv0, P0, faithful=False, lam=orc.lambda_dense(f0, m, th[0]))
+    Xc = np.random.default_rng(100 + m).random((M, D))
+    mu0, var0 = orc.predict_mean_var(Xc, X, th, Sinv0 @ f0, A0, "SE_kernel")
+    mustar = float(np.max(mu0)) - 0.1
+    out = eng.predict(post, Xc, score=1, mustar=mustar, want_score=True)      # PPBO_SCORE_POINTWISE_EI
+    assert rel(host(out["mu"]), mu0) < 1e-7
+    assert np.abs(host(out["var"]) - var0).max() <= 1e-7 * th[2] ** 2
+    sc = host(out["score"])
+    assert out["best_idx"] == int(np.argmax(sc)) and out["best_val"] == sc[out["best_idx"]]
+    sc0 = orc.pointwise_ei(mu0, var0, mustar)
+    assert np.abs(sc - sc0).max() <= 1e-6 * max(np.abs(sc0).max(), 1e-12)
+    # the same candidates in two calls of other lengths (other padding, other tile counts): the same bits
+    k = M // 2 + 1
+    a, b = eng.predict(post, Xc[:k], want_best=False), eng.predict(post, Xc[k:], want_best=False)
+    assert np.array_equal(np.concatenate([host(a["var"]), host(b["var"])]), host(out["var"]))
+    assert np.array_equal(np.concatenate([host(a["mu"]), host(b["mu"])]), host(out["mu"]))
+
+
 @pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 200, 256, 320, 449, 512, 650, 1031, 2048, 2500, 2816, 3000])
 def test_factor_triangular_inverse_and_inverse_together(eng, N):
     """ppbo_pd_inverse_ex hands back L, L^-1 and A^-1 from ONE enqueue (factorization, recursive-doubling triangular
