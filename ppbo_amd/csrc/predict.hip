@@ -319,6 +319,24 @@ __global__ __launch_bounds__(256) void pad_square_kernel(const double* __restric
   *reinterpret_cast<double2*>(Gp + (size_t)i * cols_p + j) = v;
 }
 
+// G of the model as the block-triangular products want it: rows up to a whole 128-row tile, columns up to the chunk
+// depth, framed with zeros -- the model's own array when it already has that shape.  *Nk_out = its row stride = K extent.
+// worth = false (few columns on the other side of the product: the copy would cost more than the guarded loop does):
+// the model's own array, whatever its shape.
+const double* padded_G(ppbo_ctx* ctx, const ppbo_model* model, int row_tile, bool worth, int* Nk_out, int* g_rows_out,
+                       hipStream_t s) {
+  const int N = model->N;
+  const int Nk = (N + BK - 1) & ~(BK - 1);
+  const int g_rows = ((N + row_tile - 1) / row_tile) * row_tile;
+  *Nk_out = N; *g_rows_out = N;
+  if (!worth || (g_rows == N && Nk == N && (reinterpret_cast<uintptr_t>(model->d_G) & 15) == 0)) return model->d_G;
+  *Nk_out = Nk; *g_rows_out = g_rows;
+  double* Gp = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_GPAD, (size_t)g_rows * Nk * sizeof(double));
+  if (!Gp) return nullptr;
+  pad_square_kernel<<<dim3((Nk / 2 + 255) / 256, g_rows), 256, 0, s>>>(model->d_G, N, Gp, g_rows, Nk);
+  return Gp;
+}
+
 // Z = Lambda K*  (star-graph rows), Kt/Z are [N, M] with row stride ld
 __global__ void lam_apply_kernel(const double* __restrict__ Kt, int ld, int N, int M, int mblk,
                                  const double* __restrict__ lam_diag, const double* __restrict__ lam_off,
@@ -779,9 +797,13 @@ static int predict_passes(ppbo_ctx* ctx, const ppbo_model* model, const double* 
   // cost 23 % at N = 2080, profiles/r05_ragged_shapes.txt): K extent Nk = N rounded up to the chunk depth (K* rows
   // [N, Nk) zeroed), G's rows up to a whole row tile (copied into a zero frame when N itself is not one), K*'s row
   // stride up to a whole candidate tile (the surplus columns feed only their own, unread, outputs).
-  const int Nk = (N + BK - 1) & ~(BK - 1);
-  const int g_rows = ntm * qf_bm;
-  const bool pad_g = want_var && (g_rows != N || Nk != N || (reinterpret_cast<uintptr_t>(model->d_G) & 15) != 0);
+  int Nk = N, g_rows = N;
+  const double* Gq = nullptr;
+  if (want_var) {
+    Gq = padded_G(ctx, model, qf_bm, M >= 2048, &Nk, &g_rows, s);
+    if (!Gq) return (int)hipErrorOutOfMemory;
+    PPBO_LAUNCH_CHECK(ctx);
+  }
 
   // workspaces sized for the largest chunk
   const int Mc_max = (int)(M < chunk_cap ? M : chunk_cap);
@@ -794,14 +816,6 @@ static int predict_passes(ppbo_ctx* ctx, const ppbo_model* model, const double* 
     Kt = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_KSTAR, (size_t)Nk * ldk * sizeof(double));
     if (!Kt) return (int)hipErrorOutOfMemory;
     if (Nk != N) PPBO_HIP_CHECK(ctx, hipMemsetAsync(Kt + (size_t)N * ldk, 0, (size_t)(Nk - N) * ldk * sizeof(double), s));
-  }
-  const double* Gq = model->d_G;
-  if (pad_g) {
-    double* Gp = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_GPAD, (size_t)g_rows * Nk * sizeof(double));
-    if (!Gp) return (int)hipErrorOutOfMemory;
-    pad_square_kernel<<<dim3((Nk / 2 + 255) / 256, g_rows), 256, 0, s>>>(model->d_G, N, Gp, g_rows, Nk);
-    PPBO_LAUNCH_CHECK(ctx);
-    Gq = Gp;
   }
   const size_t part_doubles = (size_t)(2 * n_split_eff + ntm) * Mc_max;
   double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_PART, part_doubles * sizeof(double));
@@ -824,7 +838,7 @@ static int predict_passes(ppbo_ctx* ctx, const ppbo_model* model, const double* 
     PPBO_LAUNCH_CHECK(ctx);
     if (want_var) {
       PpboProfScope pf(ctx, ppbo_ctx::PF_QUADFORM, s);
-      if (int rc = dispatch_quadform(ctx, Gq, pad_g ? Nk : N, pad_g ? g_rows : N, N, Kt, ldk, Mc, mblk, slab, s)) return rc;
+      if (int rc = dispatch_quadform(ctx, Gq, Nk, g_rows, N, Kt, ldk, Mc, mblk, slab, s)) return rc;
     }
     const int sblocks = score_blocks(Mc);
     PpboProfScope pfs(ctx, ppbo_ctx::PF_SCORE, s);
@@ -975,11 +989,18 @@ int line_acq_impl(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
   const int N = model->N, mblk = model->m + 1, n_q = N / mblk, D = model->D;
   const KernParams p = make_kern_params(model->kernel_id, model->theta);
   const int Bc_max = (B < 512) ? B : 512;
-  const int ld = ((Bc_max * G) + 1) & ~1;
-  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_KSTAR, (size_t)2 * N * ld * sizeof(double));
+  // operands of Y = G K* padded to whole tiles / chunks, as in predict_passes: every tile of that product then takes
+  // the unguarded loop whatever N, the star size and B G are (m = 25: 4.16 -> 3.6 ms for 512 lines at N = 2080)
+  int Nk = N, g_rows = N;
+  const double* Gq = padded_G(ctx, model, 128, (long long)B * G >= 2048, &Nk, &g_rows, s);
+  if (!Gq) return (int)hipErrorOutOfMemory;
+  PPBO_LAUNCH_CHECK(ctx);
+  const int ld = ((Bc_max * G) + 127) & ~127;
+  double* ws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_KSTAR, (size_t)(Nk + g_rows) * ld * sizeof(double));
   if (!ws) return (int)hipErrorOutOfMemory;
   double* Kt = ws;
-  double* Y = ws + (size_t)N * ld;
+  double* Y = ws + (size_t)Nk * ld;
+  if (Nk != N) PPBO_HIP_CHECK(ctx, hipMemsetAsync(Kt + (size_t)N * ld, 0, (size_t)(Nk - N) * ld * sizeof(double), s));
   double* gridws = nullptr;
   if (!d_grid) {
     gridws = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH, (size_t)Bc_max * G * D * sizeof(double));
@@ -1039,8 +1060,9 @@ int line_acq_impl(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
     }
     PPBO_LAUNCH_CHECK(ctx);
     GemmArgs y{};  // Y = G K*
-    y.A = model->d_G; y.lda = N; y.B = Kt; y.ldb = ld; y.C = Y; y.ldc = ld;
-    y.M = N; y.N = M; y.K = N; y.alpha = 1.0; y.beta = 0.0; y.khi_mode = 1; y.tri_block = mblk;
+    y.A = Gq; y.lda = Nk; y.B = Kt; y.ldb = ld; y.C = Y; y.ldc = ld;
+    y.M = g_rows; y.N = (M + 127) & ~127; y.K = Nk; y.alpha = 1.0; y.beta = 0.0; y.khi_mode = 1; y.tri_block = mblk;
+    // (rows [N, g_rows) of Y come out as zeros, columns [M, y.N) as whatever the K* padding holds: neither is read)
     // column tiles in chunks through all row tiles, heaviest first (a chunk's slice of K* -- 134 MB at 64 tiles -- stays
     // in the Infinity Cache); equal chunks of at most 72 tiles: a ragged last chunk costs 5 % (512 lines: 280 tiles in
     // chunks of 70: 2.33 ms; 64 + ragged 24: 2.47; 56: 2.35; 96: 2.35; 128: 4.85; one chunk: 4.2)

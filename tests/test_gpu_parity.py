@@ -687,6 +687,47 @@ def test_line_acq_shapes(eng, golden, B, G, S):
         assert host(ei2)[-1] == host(ei2)[0] and host(vm2)[-1] == host(vm2)[0]
 
 
+@pytest.mark.parametrize("m,n_q,B,G", [(25, 10, 40, 70), (25, 7, 3, 70), (9, 13, 33, 64), (30, 5, 50, 48), (25, 21, 30, 70)])
+def test_line_acq_ragged_star_sizes(eng, m, n_q, B, G):
+    """Line acquisitions on posteriors whose star size divides neither the chunk depth nor the row tile (m = 25 is the
+    reference's default): from B G >= 2048 grid points on, Y = G K* runs on the zero-framed G with K* and Y padded to
+    whole tiles; below, on the model's own array through the guarded loop.  Both against the full covariance
+    (ppbo_predict_cov) + the oracle's Monte-Carlo statements on the same draws."""
+    D = 4
+    th = [0.3, 0.6, 0.8]
+    X = orc.synthetic_design(n_q, D, m=m, seed=7 * m + n_q)
+    N = X.shape[0]
+    S0 = orc.gram(X, th, "SE_kernel")
+    Sinv0 = orc.pd_inverse(S0)
+    f_init = np.random.default_rng(m).multivariate_normal(np.zeros(N), S0, method="cholesky")
+    f0, _ = orc.fit_fmap_trust_exact(f_init, Sinv0, m, th[0], gtol=1e-9)
+    post = eng.posterior(X, th, "SE_kernel", eng.pd_inverse(eng.gram(X, th, "SE_kernel")), f0, m)
+    rng = np.random.default_rng(B * G + m)
+    al = np.sort(rng.random(G))
+    xis = np.zeros((B, D)); xis[np.arange(B), rng.integers(0, D, B)] = 1.0
+    xs = rng.random((B, D)) * (xis == 0)
+    grid = al[None, :, None] * xis[:, None, :] + xs[:, None, :]
+    z = rng.standard_normal((150, G))
+    sf2 = th[2] ** 2
+    mu_all = host(eng.predict(post, grid.reshape(-1, D), want_var=False, want_best=False)["mu"])
+    mustar, jit = float(mu_all.max()) - 0.05, 1e-9 * sf2
+    ei, vm = eng.line_acq(post, grid, z, mustar, jitter=jit)
+    ei2, vm2 = eng.line_acq_xi(post, xis, xs, al, z, mustar, jitter=jit)
+    assert np.array_equal(host(ei), host(ei2)) and np.array_equal(host(vm), host(vm2))
+    ei, vm = host(ei), host(vm)
+    P0 = orc.posterior_covariance(Sinv0, f0, m, th[0])
+    A0 = orc.variance_operator(Sinv0, P0, faithful=False, lam=orc.lambda_dense(f0, m, th[0]))
+    for b in sorted(set([0, B // 2, B - 1])):
+        mu_b, cov_b = eng.predict_cov(post, grid[b])
+        Ks = orc.cross_cov(X, grid[b], th, "SE_kernel")
+        cov0 = orc.gram(grid[b], th, "SE_kernel") - Ks.T @ A0 @ Ks      # the reference's Sigma_pred (gp_model.py:441-452)
+        assert np.abs(host(cov_b) - cov0).max() <= 1e-7 * sf2
+        e0 = orc.line_ei(host(mu_b), host(cov_b), z, mustar, jitter=jit)
+        v0 = orc.line_varmax(host(mu_b), host(cov_b), z, jitter=jit)
+        assert abs(ei[b] - e0) <= 1e-6 * max(abs(e0), 1e-3 * np.sqrt(sf2)), (b, ei[b], e0)
+        assert abs(vm[b] - v0) <= 1e-5 * max(abs(v0), 1e-6 * sf2), (b, vm[b], v0)
+
+
 @pytest.mark.parametrize("D", [1, 11, 13, 17, 23, 24, 30, 33, 47, 48, 50, 64])
 @pytest.mark.parametrize("kernel", ["SE_kernel", "RQ_kernel"])
 def test_every_dimension_bucket(eng, D, kernel):
@@ -752,7 +793,7 @@ def test_variance_contraction_fast_path_star_sizes(eng, m):
 
 
 @pytest.mark.parametrize("m,n_q,M", [(25, 5, 100), (25, 10, 257), (25, 21, 1000), (9, 13, 129), (2, 43, 128), (30, 9, 640),
-                                     (25, 40, 1111), (40, 7, 300), (12, 20, 4097)])
+                                     (25, 40, 1111), (40, 7, 300), (12, 20, 4097), (25, 10, 2500), (9, 13, 2048), (25, 3, 2049)])
 def test_variance_contraction_ragged_shapes(eng, m, n_q, M):
     """Star sizes that divide neither the 16-deep chunk nor the 128-row tile (m = 25 is the reference's default,
     src/ppbo_settings.py:14: N = 26 n_q), N off every tile edge, candidate counts off the 128-column tile: the
