@@ -261,15 +261,34 @@ __global__ __launch_bounds__(256) void g_build_kernel(const double* __restrict__
     if (in) G[(size_t)blockIdx.y * N + j] = obs ? t : rj * ld + r0 * lo;
     return;
   }
+  auto rr = [&](int k) { return k < lim ? r[k] : 0.0; };
+  // any other star size up to 64 rows (m = 25, the reference's default: 26): the products r_k lam_off_k of this
+  // workgroup's 256 columns and of the 64 behind them go through LDS once, so that an observation column adds up its
+  // star from there in the same order (the loop over global memory below, kept for larger stars, held its whole wavefront for
+  // mblk dependent round trips: ~100 us per posterior at N = 2080)
+  __shared__ double sp[256 + 64];
+  const bool via_lds = mblk <= 64;
+  if (via_lds) {
+    const int jb = blockIdx.x * 256;
+    for (int t = threadIdx.x; t < 256 + 64; t += 256) {
+      const int k = jb + t;
+      sp[t] = (k < N) ? rr(k) * lam_off[k] : 0.0;
+    }
+    __syncthreads();
+  }
   if (j >= N) return;
   const int q0 = (j / mblk) * mblk;
-  auto rr = [&](int k) { return k < lim ? r[k] : 0.0; };
   double acc = rr(j) * lam_diag[j];
   if (j != q0) {
     acc += rr(q0) * lam_off[j];
   } else {
     const int end = (q0 + mblk < N) ? q0 + mblk : N;
-    for (int k = q0 + 1; k < end; ++k) acc += rr(k) * lam_off[k];
+    if (via_lds) {
+      const double* spj = sp + threadIdx.x;
+      for (int k = 1; k < end - q0; ++k) acc += spj[k];
+    } else {
+      for (int k = q0 + 1; k < end; ++k) acc += rr(k) * lam_off[k];
+    }
   }
   G[(size_t)blockIdx.y * N + j] = acc;
 }

@@ -73,7 +73,7 @@ struct PpboDotsOut {
 int ppbo_gemv_async(ppbo_ctx* ctx, const double* d_T, int N, int ldt, const double* d_x, double* d_y, int trans,
                     int lower, hipStream_t s, PpboGate gate = PpboGate());
 // u = L^T beta(f) in two launches with beta[N] and tq[N / mblk] as by-products (one launch less than laplace_kernel +
-// ppbo_gemv_async); returns 1 without enqueueing anything when mblk is not a multiple of 16 or exceeds 64.
+// ppbo_gemv_async); returns 1 without enqueueing anything when a star (mblk rows) exceeds one wavefront.
 // With d_R: the first launch also carries rv = R f (full N x N, by rows) behind its own gate -- a second product with
 // the same f that would otherwise be a launch of its own
 int ppbo_gemvT_beta_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, const double* d_f, int mblk, double sigma,

@@ -799,8 +799,7 @@ __global__ __launch_bounds__(256) void gemvT_partial_kernel(const double* __rest
 
 // u = L^T beta(f), first pass, with beta REBUILT PER WORKGROUP from f instead of read from a vector that a launch of its
 // own (laplace_kernel) would have to write first: one launch less per evaluation of the whitened f_MAP search.
-// Requires mblk % GT_ROWS == 0 and mblk <= 64: a split (GT_ROWS rows) then lies inside one star, whose rows fit one
-// wavefront: lane r-1 holds pseudo-observation row r exactly as in laplace_kernel (src/gp_model.py:228-240: beta_j =
+// Requires mblk <= 64: a star's rows fit one wavefront -- lane r-1 holds pseudo-observation row r exactly as in laplace_kernel (src/gp_model.py:228-240: beta_j =
 // -phi2(Delta_j) / (sigma m) on pseudo rows, beta_obs = sum_j phi2(Delta_j) / (sigma m)), same wave_sum, same bits.
 // The workgroups of the first column block also publish beta (the judgement needs it for |grad_f|) and, one per star,
 // the likelihood sum tq[q] = sum_j Phi(Delta_j / sqrt2) (:221-226).
@@ -822,27 +821,36 @@ __global__ __launch_bounds__(256) void gemvT_beta_partial_kernel(const double* _
   __shared__ double sb[GT_ROWS];
   const int i0 = blockIdx.y * GT_ROWS;
   if (i0 + GT_ROWS <= (int)blockIdx.x * 256) return;      // no row of this split reaches these columns
-  const int q0 = (i0 / mblk) * mblk, m = mblk - 1;
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x, r = lane + 1;
-    const bool pub = blockIdx.x == 0;
-    const double f0 = f[q0];
-    double p2 = 0.0, ph = 0.0;
-    if (r <= m && q0 + r < N) {
-      const double delta = (f[q0 + r] - f0) / sigma;
-      p2 = 0.28209479177387814347 * exp(-0.25 * (delta * delta));
-      if (pub && i0 == q0) ph = 0.5 * erfc(-0.5 * delta);
-    }
+  const int m = mblk - 1;
+  {
+    // the stars that reach into this split (one when the star size is a multiple of GT_ROWS, two for e.g. the
+    // reference's default m = 25, more for tiny stars), one wavefront each.  A star is PUBLISHED (beta_out, tq) by the
+    // one split that holds its observation row.
+    const int i_last = (i0 + GT_ROWS < N ? i0 + GT_ROWS : N) - 1;
+    const int qa = i0 / mblk, qb = i_last / mblk;
+    const int lane = threadIdx.x & 63, r = lane + 1;
     const double bsc = sigma * (double)m;
-    const double sp2 = wave_sum(p2);
-    if (r <= m) {
-      const int k = q0 + r - i0;
-      if (k >= 0 && k < GT_ROWS) { sb[k] = -p2 / bsc; if (pub && q0 + r < N) beta_out[q0 + r] = -p2 / bsc; }
-    }
-    if (lane == 0 && q0 == i0) { sb[0] = sp2 / bsc; if (pub) beta_out[q0] = sp2 / bsc; }
-    if (pub && i0 == q0) {
-      const double sphi = wave_sum(ph);
-      if (lane == 0) tq[q0 / mblk] = sphi;
+    for (int q = qa + (int)(threadIdx.x >> 6); q <= qb; q += 4) {
+      const int q0 = q * mblk;
+      const bool pub = blockIdx.x == 0 && q0 >= i0;
+      const double f0 = f[q0];
+      double p2 = 0.0, ph = 0.0;
+      if (r <= m) {
+        const double delta = (f[q0 + r] - f0) / sigma;
+        p2 = 0.28209479177387814347 * exp(-0.25 * (delta * delta));
+        if (pub) ph = 0.5 * erfc(-0.5 * delta);
+      }
+      const double sp2 = wave_sum(p2);
+      if (r <= m) {
+        const int k = q0 + r - i0;
+        if (k >= 0 && k < GT_ROWS) sb[k] = -p2 / bsc;
+        if (pub) beta_out[q0 + r] = -p2 / bsc;
+      }
+      if (lane == 0 && q0 >= i0) { sb[q0 - i0] = sp2 / bsc; if (pub) beta_out[q0] = sp2 / bsc; }
+      if (pub) {
+        const double sphi = wave_sum(ph);
+        if (lane == 0) tq[q] = sphi;
+      }
     }
   }
   __syncthreads();
@@ -1136,7 +1144,7 @@ int ppbo_gemv_rect_async(ppbo_ctx* ctx, const double* d_T, int rows, int cols, i
 int ppbo_gemvT_beta_async(ppbo_ctx* ctx, const double* d_L, int N, int ldl, const double* d_f, int mblk, double sigma,
                           double* d_u, double* d_beta, double* d_tq, hipStream_t s, PpboGate gate, const double* d_R,
                           int ldr, double* d_rv, PpboGate rider_gate, PpboDotsOut dots, int* n_dot_parts) {
-  if (mblk % GT_ROWS != 0 || mblk > 64 || N % mblk != 0) return 1;
+  if (mblk > 64 || N % mblk != 0) return 1;      // a star's pseudo-observations fit one wavefront
   const int n_split = (N + GT_ROWS - 1) / GT_ROWS;
   double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_VEC, (size_t)n_split * N * sizeof(double));
   if (!part) return (int)hipErrorOutOfMemory;

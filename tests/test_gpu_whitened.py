@@ -233,3 +233,32 @@ def test_random_models_whitened_vs_trust_region(eng, block):
                 print("trust region and SciPy trust-exact in different basins:", tag, "T(scipy) =",
                       orc.T_value(f0, host(Sinv), m, sig))
     assert differ <= 4 and differ_scipy <= 1
+
+
+@pytest.mark.parametrize("m,n_q", [(25, 64), (25, 79), (3, 400), (1, 800), (47, 33), (63, 26), (9, 161)])
+def test_whitened_search_above_1536_rows_at_any_star_size(eng, m, n_q):
+    """Above N = 1536 an evaluation of the whitened search forms u = L^T beta(f) with beta rebuilt inside the product's
+    first pass (gemvT_beta_partial_kernel).  That launch used to need stars of 16, 32, 48 or 64 rows (m = 31 of the
+    BASELINE configs); m = 25 -- the reference's default, src/ppbo_settings.py:14 -- fell back to three more launches
+    per evaluation.  Now every split of 16 rows rebuilds the (up to a few) stars that reach into it: the search must
+    land where the trust region alone does from the same start, and beta / the likelihood sums it publishes must be
+    the ones ppbo_laplace_terms computes at that point."""
+    import oracle.ppbo_oracle as orc
+    D = 5
+    th = [0.2, 0.5, 0.7]
+    X = orc.synthetic_design(n_q, D, m=m, seed=m + n_q)
+    N = X.shape[0]
+    assert N > 1536 and N == n_q * (m + 1)
+    S = eng.gram(X, th, "SE_kernel")
+    Sinv, L = eng.pd_inverse_chol(S)
+    f_init = host(eng.dgemv(L, np.random.default_rng(m).standard_normal(N), lower=True))
+    fw, sw = eng.fit_fmap(Sinv, f_init, m, th[0], gtol=1e-6, L=L)
+    ft, stt = eng.fit_fmap(Sinv, f_init, m, th[0], gtol=1e-6)
+    assert sw["converged"] and stt["converged"] and sw["lbfgs_evals"] > 5
+    T, grad = eng.T_and_grad(Sinv, fw, m, th[0])
+    assert np.linalg.norm(host(grad)) < 1e-5
+    assert abs(T - sw["T"]) <= 1e-8 * max(1.0, abs(T))          # phi(z) of the search = -T(f) of the separate kernels
+    post = eng.posterior(X, th, "SE_kernel", Sinv, ft, m, want_P=True)
+    gap = sum(np.abs(host(post.P) @ host(eng.T_and_grad(Sinv, f, m, th[0])[1])).max() for f in (fw, ft))
+    assert np.abs(host(fw) - host(ft)).max() <= 1e-5 * np.abs(host(ft)).max() + 1.5 * gap
+    assert abs(sw["T"] - stt["T"]) <= 1e-8 * max(1.0, abs(stt["T"]))
