@@ -419,9 +419,9 @@ __device__ __forceinline__ void lc_mfma_y(const double (&fy)[NT16], double4_t (&
 template <int NT16, bool SYM, int W, int LDC>
 __device__ __forceinline__ void line_cov_mm(const double* Ks, const double* Bs, const double* Ys, int lk, int lr,
                                             double4_t (&accK)[(LcTiles<NT16, SYM>::N + 3) / 4],
-                                            double4_t (&accY)[(LcTiles<NT16, SYM>::N + 3) / 4]) {
+                                            double4_t (&accY)[(LcTiles<NT16, SYM>::N + 3) / 4], int ksteps) {
 #pragma unroll 1
-  for (int kk = 0; kk < 8; ++kk) {          // not unrolled: 3 NT16 fragments per step are live, not 24 NT16
+  for (int kk = 0; kk < ksteps; ++kk) {     // not unrolled: 3 NT16 fragments per step are live, not 24 NT16
     const int ko = (4 * kk + lk) * LDC + lr;
     // this k-step's fragments of all NT16 column blocks, once: every tile of the wavefront draws on them
     double fk[NT16], fb[NT16], fy[NT16];
@@ -434,14 +434,16 @@ __device__ __forceinline__ void line_cov_mm(const double* Ks, const double* Bs, 
 
 constexpr int LC_MAXROWS = 512;      // rows of one (line, slice) workgroup: their Lambda entries sit in LDS
 
-// SYM (the host picks it when mblk == 32 and the row slices are 32-aligned: every chunk is exactly one star): Lambda K*
-// is formed EXACTLY -- the observation row gets lam_obs k_obs + sum_j lam_off,j k_j from the staged chunk -- so that both
-// products are symmetric and only the tiles of the lower triangle (15 of 25 at G = 70) are computed.
+// SYM (the host picks it for stars of up to 32 rows, with row slices that hold whole stars): a chunk is `cs` rows = as many
+// WHOLE stars as fit 32 rows (one at m = 31 and at the reference's default m = 25, two at m = 15, ...; the rest of the 32
+// staged rows are zeros and k-steps beyond them are not run), so Lambda K* is formed EXACTLY -- every observation row gets
+// lam_obs k_obs + sum_j lam_off,j k_j from the staged chunk -- both products are symmetric and only the tiles of the
+// lower triangle (15 of 25 at G = 70) are computed.  Not SYM: cs = 32 rows of anything, the one-sided form.
 template <int NT16, bool SYM>
 __global__ __launch_bounds__(256, (NT16 <= 5) ? 2 : 1) void line_cov_kernel(const double* __restrict__ Kt, const double* __restrict__ Y, int ld,
                                                           int N, int G, int mblk, const double* __restrict__ lam_diag,
                                                           const double* __restrict__ lam_off, int rows_per_split,
-                                                          double* __restrict__ out, long long out_stride) {
+                                                          double* __restrict__ out, long long out_stride, int cs) {
   using TL = LcTiles<NT16, SYM>;
   constexpr int CH = 32, LDC = 16 * NT16 + 8, NTILE = TL::N, TPW = (NTILE + 3) / 4;
   constexpr int NQ = (CH * 16 * NT16 + 255) / 256;
@@ -484,13 +486,14 @@ __global__ __launch_bounds__(256, (NT16 <= 5) ? 2 : 1) void line_cov_kernel(cons
     }
   };
   fetch(r_beg);
-  for (int row0 = r_beg; row0 < r_end; row0 += CH) {
+  const int ksteps = (cs + 3) >> 2;
+  for (int row0 = r_beg; row0 < r_end; row0 += cs) {
     __syncthreads();                         // the previous chunk's operands are done with (and, first time, s_ld / s_lo are there)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int r = rq[q], j = row0 + r;
       if (r < CH) {
-        const bool on = j < r_end;
+        const bool on = r < cs && j < r_end;
         const int jl = on ? j - r_beg : 0;
         const double kv = on ? rk[q] : 0.0;
         // Lambda row: lam_jj k_j + c lam_off,j k_obs (lam_off is 0 on observation rows); c = 2: the one-sided form,
@@ -502,24 +505,27 @@ __global__ __launch_bounds__(256, (NT16 <= 5) ? 2 : 1) void line_cov_kernel(cons
     }
     __syncthreads();
     if (SYM) {
-      // the chunk is one star, row 0 its observation: B[0][g] += sum_r lam_off,r K[r][g] (31 terms per column)
+      // the chunk is whole stars, each led by its observation row o: B[o][g] += sum_r lam_off,o+r K[o+r][g] (m terms per
+      // column; rows past the slice's end were staged as zeros and are not touched)
       if (t < 16 * NT16) {
-        double sg = 0.0;
         const int jl0 = row0 - r_beg;
+        for (int o = 0; o < cs && row0 + o < r_end; o += mblk) {
+          double sg = 0.0;
 #pragma unroll 8
-        for (int r = 1; r < CH; ++r) sg += s_lo[jl0 + r] * Ks[r * LDC + t];
-        Bs[t] += sg;
+          for (int r = 1; r < mblk; ++r) sg += s_lo[jl0 + o + r] * Ks[(o + r) * LDC + t];
+          Bs[o * LDC + t] += sg;
+        }
       }
       __syncthreads();
     }
-    if (row0 + CH < r_end) fetch(row0 + CH);
+    if (row0 + cs < r_end) fetch(row0 + cs);
     // the tile list of a wavefront is a compile-time list (W + 4 i): a run-time tile index would turn the fragment
     // arrays into dynamically indexed registers (measured: 1.84 ms instead of 0.99)
     switch (wave) {
-      case 0: line_cov_mm<NT16, SYM, 0, LDC>(Ks, Bs, Ys, lk, lr, accK, accY); break;
-      case 1: line_cov_mm<NT16, SYM, 1, LDC>(Ks, Bs, Ys, lk, lr, accK, accY); break;
-      case 2: line_cov_mm<NT16, SYM, 2, LDC>(Ks, Bs, Ys, lk, lr, accK, accY); break;
-      default: line_cov_mm<NT16, SYM, 3, LDC>(Ks, Bs, Ys, lk, lr, accK, accY); break;
+      case 0: line_cov_mm<NT16, SYM, 0, LDC>(Ks, Bs, Ys, lk, lr, accK, accY, ksteps); break;
+      case 1: line_cov_mm<NT16, SYM, 1, LDC>(Ks, Bs, Ys, lk, lr, accK, accY, ksteps); break;
+      case 2: line_cov_mm<NT16, SYM, 2, LDC>(Ks, Bs, Ys, lk, lr, accK, accY, ksteps); break;
+      default: line_cov_mm<NT16, SYM, 3, LDC>(Ks, Bs, Ys, lk, lr, accK, accY, ksteps); break;
     }
   }
   double* o = out + (size_t)blockIdx.y * out_stride + (size_t)blockIdx.x * G * G;
@@ -1010,11 +1016,16 @@ int line_acq_impl(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
   const int q_per_split = (n_q + n_split - 1) / n_split;
   const int n_split_eff = (n_q + q_per_split - 1) / q_per_split;
   // row slices of the covariance's data term: enough (line, slice) workgroups for every CU to hold several
+  // a slice walks its rows in chunks of cov_cs: whole stars (as many as fit the 32 staged rows) where a star has at most
+  // 32 rows -- the symmetric form of line_cov_kernel --, else 32 rows of anything
+  const bool sym = mblk <= 32;
+  const int cov_cs = sym ? (32 / mblk) * mblk : 32;
   int cov_splits = (1024 + Bc_max - 1) / Bc_max;
   if (cov_splits < (N + LC_MAXROWS - 1) / LC_MAXROWS) cov_splits = (N + LC_MAXROWS - 1) / LC_MAXROWS;   // <= LC_MAXROWS rows per slice
-  if (cov_splits > (N + 31) / 32) cov_splits = (N + 31) / 32;
+  if (cov_splits > (N + cov_cs - 1) / cov_cs) cov_splits = (N + cov_cs - 1) / cov_cs;
   if (cov_splits < 1) cov_splits = 1;
-  const int cov_rows = ((((N + cov_splits - 1) / cov_splits) + 31) / 32) * 32;
+  int cov_rows = ((((N + cov_splits - 1) / cov_splits) + cov_cs - 1) / cov_cs) * cov_cs;
+  if (cov_rows > LC_MAXROWS) cov_rows = (LC_MAXROWS / cov_cs) * cov_cs;
   cov_splits = (N + cov_rows - 1) / cov_rows;
   double* part = (double*)ppbo_workspace(
       ctx, ppbo_ctx::WS_PART,
@@ -1073,18 +1084,17 @@ int line_acq_impl(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
       if (int rc = ppbo_gemm_launch(ctx, y, 0, 0, s)) return rc;
     }
     // data term of every line's covariance: K*' Lambda K* + Y'Y, one workgroup per (line, row slice)
-    const bool sym = (mblk == 32) && (cov_rows % 32 == 0);
     {
       PpboProfScope pf(ctx, ppbo_ctx::PF_LINE_COV, s);
       const dim3 cg(Bc, cov_splits);
       const long long pst = (long long)Bc_max * G * G;
-      // sym: every chunk of 32 rows is exactly one star: the symmetric form (lower-triangle tiles only)
+      // sym: every chunk is whole stars: the symmetric form (lower-triangle tiles only)
 #define LC_LAUNCH(NT)                                                                                                   \
   do {                                                                                                                  \
     if (sym) line_cov_kernel<NT, true><<<cg, 256, 0, s>>>(Kt, Y, ld, N, G, mblk, model->d_lam_diag, model->d_lam_off,   \
-                                                          cov_rows, cov_parts, pst);                                    \
+                                                          cov_rows, cov_parts, pst, cov_cs);                            \
     else line_cov_kernel<NT, false><<<cg, 256, 0, s>>>(Kt, Y, ld, N, G, mblk, model->d_lam_diag, model->d_lam_off,      \
-                                                       cov_rows, cov_parts, pst);                                       \
+                                                       cov_rows, cov_parts, pst, cov_cs);                               \
   } while (0)
       switch ((G + 15) / 16) {
         case 1: LC_LAUNCH(1); break;

@@ -687,7 +687,8 @@ def test_line_acq_shapes(eng, golden, B, G, S):
         assert host(ei2)[-1] == host(ei2)[0] and host(vm2)[-1] == host(vm2)[0]
 
 
-@pytest.mark.parametrize("m,n_q,B,G", [(25, 10, 40, 70), (25, 7, 3, 70), (9, 13, 33, 64), (30, 5, 50, 48), (25, 21, 30, 70)])
+@pytest.mark.parametrize("m,n_q,B,G", [(25, 10, 40, 70), (25, 7, 3, 70), (9, 13, 33, 64), (30, 5, 50, 48), (25, 21, 30, 70), (40, 5, 30, 70),
+                                       (1, 100, 8, 70), (15, 12, 35, 70), (33, 6, 30, 17), (25, 24, 600, 16)])
 def test_line_acq_ragged_star_sizes(eng, m, n_q, B, G):
     """Line acquisitions on posteriors whose star size divides neither the chunk depth nor the row tile (m = 25 is the
     reference's default): from B G >= 2048 grid points on, Y = G K* runs on the zero-framed G with K* and Y padded to
