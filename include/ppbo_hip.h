@@ -259,7 +259,10 @@ typedef struct ppbo_model {
   const double* d_alpha;    /* [N]   */
   const double* d_lam_diag; /* [N]  Lambda_MAP diagonal   */
   const double* d_lam_off;  /* [N]  Lambda_MAP star edges */
-  const double* d_G;        /* [N,N] R W, see ppbo_posterior */
+  const double* d_G;        /* [N,N] R W, see ppbo_posterior.  Block lower triangular, and stored that way: every
+                             * entry right of the last star that reaches into its row must be an explicit ZERO
+                             * (ppbo_posterior / ppbo_gp_fit write them): the contractions round their K ranges up to
+                             * whole 16-column chunks and read up to 15 of those zeros per row */
   int kstar_fp32;           /* 0: everything fp64 (the product path).  1: K* entries evaluated in fp32 from direct
                              * differences, all accumulation fp64 -- BASELINE config 5's "fp32 tolerance" variant;
                              * its error against the fp64 path is REPORTED (bench.py), it does not meet 1e-5 */
