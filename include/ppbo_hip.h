@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PPBO_ABI_VERSION 4
+#define PPBO_ABI_VERSION 5
 #define PPBO_ERR_NOT_PD 1001
 
 typedef struct ppbo_ctx ppbo_ctx;
@@ -308,6 +308,21 @@ int ppbo_mean_ascent(ppbo_ctx* ctx, const ppbo_model* model, const double* d_sta
                      double* d_x, double* d_mu, int* d_iters, void* stream);
 int ppbo_shift_points(ppbo_ctx* ctx, const double* d_in, int64_t M, int D, const double* h_shift, double* d_out,
                       void* stream);
+
+/* ALL trials of one mu_star call in one enqueue (src/gp_model.py:415-437: `mustar_finding_trials` differential-evolution
+ * runs, 3 per iteration, 20 on the last).  Trial t scores the resident uniform pool d_pool[M,D] through its own rotation
+ * frac(pool + h_shifts[t]) -- formed on the fly, nothing is written out -- and trial 0 also E_rows extra points
+ * d_extra[E_rows,D] (NULL with E_rows = N: the model's own design points) and, when h_xprev[D] is given, the previous
+ * x*; then, for all trials together: one thinning launch, one start-selection launch (a workgroup per trial), ONE ascent
+ * launch of T K workgroups.  Against T calls of ppbo_mean_search on three contexts / streams: 3 trials at C3 2.2 -> 1.1 ms.
+ * screen_fp32 = 1: the candidates are RANKED by a mean whose kernel values are evaluated in fp32 (packed fp32 math,
+ * v_exp_f32; accumulated in fp64; relative error ~1e-6) -- every reported value and point comes from the fp64 ascent;
+ * 0: ranked by the fp64 mean of ppbo_predict, as ppbo_mean_search does (bit-identical results to T such calls).
+ * d_x[T,K,D], d_mu[T,K]: the refined maxima per trial (rows that found no start: mu = -inf).  Nothing synchronises. */
+int ppbo_mean_search_multi(ppbo_ctx* ctx, const ppbo_model* model, const double* d_pool, int64_t M,
+                           const double* h_shifts, int T, const double* d_extra, int E_rows, const double* h_xprev,
+                           int K, double sep, int iters, double tol, int screen_fp32, double* d_x, double* d_mu,
+                           void* stream);
 
 /* ---- K10: Monte-Carlo line acquisition -------------------------------------
  * replaces EI / varmax (src/acquisition.py:72-81, 170-178) for B lines of G points

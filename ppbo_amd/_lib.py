@@ -75,6 +75,7 @@ SIGNATURES = {
     "ppbo_mean_search": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _i, _d, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_mean_ascent": [_vp, C.POINTER(Model), _vp, _i, _i, _d, _vp, _vp, _vp, _vp],
     "ppbo_shift_points": [_vp, _vp, _i64, _i, C.POINTER(_d), _vp, _vp],
+    "ppbo_mean_search_multi": [_vp, C.POINTER(Model), _vp, _i64, C.POINTER(_d), _i, _vp, _i, C.POINTER(_d), _i, _d, _i, _d, _i, _vp, _vp, _vp],
     "ppbo_line_acq": [_vp, C.POINTER(Model), _vp, _i, _i, _d, _vp, _i, _d, _d, _vp, _vp, _vp],
     "ppbo_line_acq_xi": [_vp, C.POINTER(Model), _vp, _vp, _vp, _i, _i, _i, _d, _vp, _i, _d, _d, _vp, _vp, _vp],
     "ppbo_randn": [_vp, C.c_uint64, _vp, _i64, _vp],
@@ -97,7 +98,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4     # must equal PPBO_ABI_VERSION of include/ppbo_hip.h
+ABI_VERSION = 5     # must equal PPBO_ABI_VERSION of include/ppbo_hip.h
 
 
 def _check_stamp():

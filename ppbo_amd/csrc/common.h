@@ -25,7 +25,7 @@ struct ppbo_ctx {
   int device = 0;
   std::string err;
   // named workspace slots
-  enum { WS_KSTAR = 0, WS_PART, WS_SCRATCH, WS_LINALG, WS_LINALG2, WS_VEC, WS_SMALL, WS_POTRF, WS_APPEND, WS_DIST, WS_LBFGS, WS_SEARCH, WS_SEARCH_SMALL, WS_LBFGS_U, WS_TRANSPOSE, WS_GPAD, WS_COUNT };
+  enum { WS_KSTAR = 0, WS_PART, WS_SCRATCH, WS_LINALG, WS_LINALG2, WS_VEC, WS_SMALL, WS_POTRF, WS_APPEND, WS_DIST, WS_LBFGS, WS_SEARCH, WS_SEARCH_SMALL, WS_LBFGS_U, WS_TRANSPOSE, WS_GPAD, WS_SEARCH_ROWS, WS_COUNT };
   void* ws[WS_COUNT] = {};
   size_t ws_bytes[WS_COUNT] = {};
   void* pinned = nullptr;  // small pinned host staging buffer

@@ -80,10 +80,142 @@ __global__ __launch_bounds__(256) void mean_grad_kernel(const double* __restrict
 //      of mu and its gradient by all 256 threads (as mean_grad_kernel), the D-vector bookkeeping by wavefront 0 with
 //      lane = coordinate (D <= 64), monotone safeguard, per-start stopping rule.
 
+// The candidates of the trials of ONE mu_star call (ppbo_mean_search_multi), never materialised: trial t sees the
+// resident uniform pool through its own rotation frac(pool + shift_t) (what ppbo_shift_points writes out for the
+// one-trial entry: the same expression, the same bits), and trial 0 also the E extra points (the design, the previous
+// x*).  Every trial has Mt = M + E slots; slots >= M of the later trials are absent (score -inf).
+struct TrialCands {
+  const double* pool = nullptr; long long M = 0; const double* shifts = nullptr;
+  const double* extra = nullptr;   // E_rows rows (the design points: the model's own X, or caller-given points) ...
+  const double* xprev = nullptr;   // ... followed by one more point (the previous x*) when given
+  int E_rows = 0, E = 0, D = 0;    // E = E_rows + (xprev ? 1 : 0)
+};
+__device__ __forceinline__ double trial_coord(const TrialCands& c, int trial, long long i, int d) {
+  if (i < c.M) { const double v = c.pool[(size_t)i * c.D + d] + c.shifts[(size_t)trial * c.D + d]; return v - floor(v); }
+  const long long e = i - c.M;
+  return e < c.E_rows ? c.extra[(size_t)e * c.D + d] : c.xprev[d];
+}
+
+// Screening pass of a mu_star trial: the posterior mean of every candidate, good enough to RANK them (the starts of the
+// ascents are picked from it; every value that is reported comes from the fp64 ascent).  Kernel values in fp32 from
+// direct differences -- v_exp_f32 instead of an 18-instruction fp64 exponential, fp32 FMAs at twice the fp64 rate --
+// accumulated in fp64 (alpha has both signs and |mu| << sum |alpha_i k_i|).  Relative error of mu ~1e-6: two candidates
+// closer than that may swap ranks.  grid (candidate blocks, row splits, trials); part[trial][split][Mt].
+constexpr int SCR_T = 256, SCR_CPT = 4, SCR_RJ = 64;
+typedef float float2_t __attribute__((ext_vector_type(2)));
+// two candidates per packed operation (v_pk_add_f32 / v_pk_fma_f32: both halves at the price of one fp32 instruction)
+template <int KID>
+__device__ __forceinline__ float2_t screen_term2(float2_t dx, int d, float c0, float c1) {
+  if (KID == PPBO_KERNEL_CAMPHOR) {
+    if (d == 2) return c1 * dx * dx;
+    float2_t sn;
+    sn.x = sinpif(fabsf(dx.x)); sn.y = sinpif(fabsf(dx.y));
+    return c0 * sn * sn;
+  }
+  return dx * dx;
+}
+template <int KID>
+__device__ __forceinline__ float screen_finish(float s, float sf2, float c0) {
+  if (KID == PPBO_KERNEL_RQ) { const float t = 1.0f + s * c0; return sf2 * __builtin_amdgcn_rcpf(t * t); }
+  const float e = (KID == PPBO_KERNEL_SE) ? -c0 * s : -s;
+  return sf2 * __builtin_amdgcn_exp2f(fmaxf(e * 1.44269504088896340736f, -126.0f));
+}
+template <int KID, int DP>
+__global__ __launch_bounds__(SCR_T) void mean_screen_kernel(const double* __restrict__ X, int N, int D, KernParams p,
+                                                            const double* __restrict__ alpha, TrialCands tc,
+                                                            int rows_per_split, int n_split, double* __restrict__ part,
+                                                            int extra_trial) {
+  static_assert(SCR_CPT % 2 == 0, "candidates in packed pairs");
+  constexpr int NP = SCR_CPT / 2;
+  __shared__ __attribute__((aligned(16))) float xs[SCR_RJ][DP];
+  __shared__ double sa[SCR_RJ];
+  const int trial = blockIdx.z;
+  const long long Mt = tc.M + tc.E;
+  const long long c0 = ((long long)blockIdx.x * SCR_T + threadIdx.x) * SCR_CPT;
+  float2_t xc[NP][DP];
+  double mu[SCR_CPT];
+#pragma unroll
+  for (int q = 0; q < SCR_CPT; ++q) {
+    mu[q] = 0.0;
+    const bool there = c0 + q < tc.M || (trial == extra_trial && c0 + q < Mt);   // (the launch's trial that carries the extra points)
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      const float v = (d < D && there) ? (float)trial_coord(tc, trial, c0 + q, d) : 0.0f;
+      if (q & 1) xc[q >> 1][d].y = v; else xc[q >> 1][d].x = v;
+    }
+  }
+  const float c0f = (float)p.c0, c1f = (float)p.c1, sf2f = (float)p.sf2;
+  const int j_beg = blockIdx.y * rows_per_split;
+  int j_end = j_beg + rows_per_split;
+  if (j_end > N) j_end = N;
+  for (int row0 = j_beg; row0 < j_end; row0 += SCR_RJ) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < SCR_RJ * DP; e += SCR_T) {
+      const int r = e / DP, d = e - r * DP, j = row0 + r;
+      xs[r][d] = (j < j_end && d < D) ? (float)X[(size_t)j * D + d] : 0.0f;
+    }
+    if (threadIdx.x < SCR_RJ) sa[threadIdx.x] = (row0 + (int)threadIdx.x < j_end) ? alpha[row0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    const int rmax = (j_end - row0 < SCR_RJ) ? (j_end - row0) : SCR_RJ;
+    for (int r = 0; r < rmax; ++r) {
+      float2_t sv[NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) sv[q] = float2_t{0.0f, 0.0f};
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        const float x = xs[r][d];
+        const float2_t xx = {x, x};
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          if (KID == PPBO_KERNEL_CAMPHOR) sv[q] += screen_term2<KID>(xx - xc[q][d], d, c0f, c1f);
+          else { const float2_t dx = xx - xc[q][d]; sv[q] = __builtin_elementwise_fma(dx, dx, sv[q]); }
+        }
+      }
+      const double a = sa[r];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        mu[2 * q] = fma(a, (double)screen_finish<KID>(sv[q].x, sf2f, c0f), mu[2 * q]);
+        mu[2 * q + 1] = fma(a, (double)screen_finish<KID>(sv[q].y, sf2f, c0f), mu[2 * q + 1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < SCR_CPT; ++q)
+    if (c0 + q < Mt) part[((size_t)trial * n_split + blockIdx.y) * Mt + c0 + q] = mu[q];
+}
+
+// mu[trial][c] = sum over the row splits (fixed order); absent slots -inf
+__global__ __launch_bounds__(256) void screen_sum_kernel(const double* __restrict__ part, int n_split, long long Mt,
+                                                         long long M, int extra_trial, double* __restrict__ mu) {
+  const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int trial = blockIdx.y;
+  if (c >= Mt) return;
+  double s = 0.0;
+  if (c >= M && trial != extra_trial) s = -INFINITY;
+  else
+    for (int k = 0; k < n_split; ++k) s += part[((size_t)trial * n_split + k) * Mt + c];
+  mu[(size_t)trial * Mt + c] = s;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(double* __restrict__ p, long long n, double v) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// candidates of trial t as rows (the fp64 screening path scores them with ppbo_predict)
+__global__ __launch_bounds__(256) void trial_rows_kernel(TrialCands tc, int trial, double* __restrict__ out) {
+  const long long n = (tc.M + (trial == 0 ? tc.E : 0)) * tc.D;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  out[e] = trial_coord(tc, trial, e / tc.D, (int)(e % tc.D));
+}
+
+// blockIdx.y = trial: mu, gval, gidx are per-trial arrays of M (resp. T) entries
 __global__ __launch_bounds__(256) void group_max_kernel(const double* __restrict__ mu, int64_t M, int G, int T,
                                                         double* __restrict__ gval, int* __restrict__ gidx) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
+  mu += (size_t)blockIdx.y * M; gval += (size_t)blockIdx.y * T; gidx += (size_t)blockIdx.y * T;
   const int64_t lo = (int64_t)t * G, hi = (lo + G < M) ? lo + G : M;
   double best = -INFINITY;
   int64_t bi = lo;
@@ -128,19 +260,24 @@ __device__ __forceinline__ SelRec wave_sel(SelRec a) {
 // (DPP per wavefront, every wavefront merges the 16 wave records itself) and a strike pass over LDS -- no global
 // round trip inside the K-step loop (the first form re-read gidx and the coordinates from memory in every step:
 // 13 us per pick, 0.44 of the 0.68 ms of a mu_star trial).
+// blockIdx.x = trial (ppbo_mean_search_multi; the one-trial entries launch one workgroup): every per-trial array is
+// offset by it, and with tc.pool the candidate coordinates are formed on the fly (TrialCands) instead of read from `cand`.
 __global__ __launch_bounds__(1024) void select_starts_kernel(const double* __restrict__ gval,
                                                              const int* __restrict__ gidx, int T,
                                                              const double* __restrict__ cand, int D, int K, double sep2,
-                                                             double* __restrict__ starts, int* __restrict__ count) {
+                                                             double* __restrict__ starts, int* __restrict__ count,
+                                                             TrialCands tc) {
   extern __shared__ double sv[];          // [T] survivor scores (struck: -inf) | [T][D] coordinates | 16 wave records
   double* xc = sv + T;
   __shared__ double wv[16];
   __shared__ int wi[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int trial = blockIdx.x;
+  gval += (size_t)trial * T; gidx += (size_t)trial * T; starts += (size_t)trial * K * D; count += trial;
   for (int t = tid; t < T; t += 1024) sv[t] = gval[t];
   for (int e = tid; e < T * D; e += 1024) {
     const int t = e / D, d = e - t * D;
-    xc[e] = cand[(size_t)gidx[t] * D + d];
+    xc[e] = tc.pool ? trial_coord(tc, trial, gidx[t], d) : cand[(size_t)gidx[t] * D + d];
   }
   __syncthreads();
   int k = 0;
@@ -292,14 +429,16 @@ template <int DP, class EVAL, int NT>
 __global__ __launch_bounds__(NT) void bb_ascent_kernel(EVAL ev, int D, const double* __restrict__ starts,
                                                         const int* __restrict__ count, int iters, double tol,
                                                         double* __restrict__ x_out, double* __restrict__ mu_out,
-                                                        int* __restrict__ it_out) {
+                                                        int* __restrict__ it_out, int per_trial) {
   static_assert(DP <= 64, "lane = coordinate");
   constexpr int NW = NT / 16;              // one record per row of 16 lanes
   __shared__ double red[NW][DP + 1];
   __shared__ double sx[DP];
   __shared__ int done;
   const int c = blockIdx.x, tid = threadIdx.x;
-  if (count && c >= *count) {
+  // count: starts that exist -- one number for the launch (per_trial = 0) or one per block of per_trial starts (the
+  // trials of ppbo_mean_search_multi)
+  if (count && (per_trial > 0 ? (c % per_trial) >= count[c / per_trial] : c >= *count)) {
     if (tid == 0) { mu_out[c] = -INFINITY; if (it_out) it_out[c] = 0; }
     return;
   }
@@ -374,7 +513,7 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(const double* __res
 
 template <int KID>
 int launch_mean_ascent(ppbo_ctx* ctx, const ppbo_model* m, const KernParams& p, const double* starts, const int* count, int K,
-                       int iters, double tol, double* x_out, double* mu_out, int* it_out, hipStream_t s) {
+                       int iters, double tol, double* x_out, double* mu_out, int* it_out, hipStream_t s, int per_trial = 0) {
   double* Xt = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_TRANSPOSE, (size_t)m->N * m->D * sizeof(double));
   if (!Xt) return (int)hipErrorOutOfMemory;
   transpose_rows_kernel<<<(m->N + 255) / 256, 256, 0, s>>>(m->d_X, m->N, m->D, Xt);
@@ -383,7 +522,7 @@ int launch_mean_ascent(ppbo_ctx* ctx, const ppbo_model* m, const KernParams& p, 
 #define MA_LAUNCH(DP, NT)                                                                                             \
   do {                                                                                                                \
     MeanEval<KID, DP, NT> ev{Xt, m->N, m->D, p, m->d_alpha};                                                        \
-    bb_ascent_kernel<DP, MeanEval<KID, DP, NT>, NT><<<K, NT, 0, s>>>(ev, m->D, starts, count, iters, tol, x_out, mu_out, it_out); \
+    bb_ascent_kernel<DP, MeanEval<KID, DP, NT>, NT><<<K, NT, 0, s>>>(ev, m->D, starts, count, iters, tol, x_out, mu_out, it_out, per_trial); \
   } while (0)
   const bool tall = m->N >= 1024;
   if (KID == PPBO_KERNEL_CAMPHOR || m->D <= 8) { if (tall) MA_LAUNCH(8, 1024); else MA_LAUNCH(8, 256); }
@@ -402,7 +541,7 @@ int launch_rff_ascent(ppbo_ctx* ctx, const double* W_rows, int F, int D, const d
 #define RA_LAUNCH(DP, NT)                                                                                      \
   do {                                                                                                         \
     RffEval<DP, NT> ev{W, F, D, b, omega, amp, make_rff_poly(1.0)};                                            \
-    bb_ascent_kernel<DP, RffEval<DP, NT>, NT><<<K, NT, 0, s>>>(ev, D, starts, count, iters, tol, x_out, v_out, nullptr); \
+    bb_ascent_kernel<DP, RffEval<DP, NT>, NT><<<K, NT, 0, s>>>(ev, D, starts, count, iters, tol, x_out, v_out, nullptr, 0); \
   } while (0)
   const bool wide = F >= 1024;
   if (D <= 8) { if (wide) RA_LAUNCH(8, 1024); else RA_LAUNCH(8, 256); }
@@ -513,7 +652,7 @@ extern "C" int ppbo_mean_search(ppbo_ctx* ctx, const ppbo_model* m, const double
   {
     const size_t sel_lds = (size_t)T * (1 + D) * sizeof(double);
     if (sel_lds > 64 * 1024) ppbo_lds_limit(ctx, (const void*)select_starts_kernel, 150 * 1024);
-    select_starts_kernel<<<1, 1024, sel_lds, s>>>(gval, gidx, T, d_cand, D, K, sep * sep, starts, count);
+    select_starts_kernel<<<1, 1024, sel_lds, s>>>(gval, gidx, T, d_cand, D, K, sep * sep, starts, count, TrialCands{});
   }
   const KernParams p = make_kern_params(m->kernel_id, m->theta);
   switch (m->kernel_id) {
@@ -529,6 +668,132 @@ extern "C" int ppbo_mean_search(ppbo_ctx* ctx, const ppbo_model* m, const double
   return 0;
 }
 
+
+template <int KID>
+void launch_screen(const ppbo_model* m, const KernParams& p, const TrialCands& tc, int nb, int rows_per_split, int n_split,
+                   double* part, int extra_trial, hipStream_t s) {
+  const long long Mt = tc.M + tc.E;
+  const dim3 grid((unsigned)((Mt + SCR_T * SCR_CPT - 1) / (SCR_T * SCR_CPT)), n_split, nb);
+#define SCR_LAUNCH(DP) mean_screen_kernel<KID, DP><<<grid, SCR_T, 0, s>>>(m->d_X, m->N, m->D, p, m->d_alpha, tc, rows_per_split, n_split, part, extra_trial)
+  if (KID == PPBO_KERNEL_CAMPHOR) SCR_LAUNCH(6);
+  else if (m->D <= 4) SCR_LAUNCH(4);
+  else if (m->D <= 8) SCR_LAUNCH(8);
+  else if (m->D <= 12) SCR_LAUNCH(12);
+  else if (m->D <= 16) SCR_LAUNCH(16);
+  else if (m->D <= 20) SCR_LAUNCH(20);
+  else if (m->D <= 24) SCR_LAUNCH(24);
+  else if (m->D <= 32) SCR_LAUNCH(32);
+  else if (m->D <= 48) SCR_LAUNCH(48);
+  else SCR_LAUNCH(64);
+#undef SCR_LAUNCH
+}
+
+extern "C" int ppbo_mean_search_multi(ppbo_ctx* ctx, const ppbo_model* m, const double* d_pool, int64_t M,
+                                      const double* h_shifts, int T, const double* d_extra, int E_rows,
+                                      const double* h_xprev, int K, double sep, int iters, double tol, int screen_fp32,
+                                      double* d_x, double* d_mu, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, m != nullptr && m->d_X && m->d_alpha, "model X/alpha");
+  PPBO_REQUIRE(ctx, m->N > 0 && m->D > 0 && m->D <= 64, "model sizes (D<=64)");
+  PPBO_REQUIRE(ctx, m->kernel_id >= 0 && m->kernel_id <= 2, "kernel_id");
+  PPBO_REQUIRE(ctx, m->kernel_id != PPBO_KERNEL_CAMPHOR || m->D == 6, "camphor kernel needs D == 6");
+  PPBO_REQUIRE(ctx, d_pool && h_shifts && d_x && d_mu && M > 0 && E_rows >= 0 && M + E_rows + 1 < ((int64_t)1 << 31),
+               "pool / shifts / extra points / outputs");
+  if (E_rows > 0 && !d_extra) {       // NULL with a row count: the model's own design points
+    PPBO_REQUIRE(ctx, E_rows == m->N, "d_extra = NULL stands for the model's N design points: E_rows must be N");
+    d_extra = m->d_X;
+  }
+  const int E = E_rows + (h_xprev ? 1 : 0);
+  PPBO_REQUIRE(ctx, T >= 1 && T <= 64 && K > 0 && K <= 1024 && sep >= 0 && iters >= 0 && tol >= 0, "T (<= 64) / K (<= 1024) / sep / iters / tol");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = m->D;
+  const long long Mt = M + E;
+  const int T_MAX = select_capacity(D);
+  const int G = (int)((Mt + T_MAX - 1) / T_MAX);
+  const int Tg = (int)((Mt + G - 1) / G);
+  // workspace: shifts[T][D] + xprev[D] | mu[T][Mt] | gval[T][Tg] | starts[T][K][D] | gidx[T][Tg] (int) | counts[T] (int)
+  const size_t nd = (size_t)(T + 1) * D + (size_t)T * Mt + (size_t)T * Tg + (size_t)T * K * D;
+  double* base = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH, nd * sizeof(double) + ((size_t)T * Tg + T + 16) * sizeof(int));
+  if (!base) return (int)hipErrorOutOfMemory;
+  double* shifts = base;
+  double* xprev = shifts + (size_t)T * D;
+  double* mu = xprev + D;
+  double* gval = mu + (size_t)T * Mt;
+  double* starts = gval + (size_t)T * Tg;
+  int* gidx = (int*)(starts + (size_t)T * K * D);
+  int* counts = gidx + (size_t)T * Tg;
+  {
+    // the shifts and the previous x* leave the host in ONE copy (pageable memory: the runtime has consumed the buffer
+    // when hipMemcpyAsync returns)
+    std::vector<double> stage((size_t)(T + 1) * D);
+    std::memcpy(stage.data(), h_shifts, (size_t)T * D * sizeof(double));
+    if (h_xprev) std::memcpy(stage.data() + (size_t)T * D, h_xprev, (size_t)D * sizeof(double));
+    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(shifts, stage.data(), (size_t)(T + (h_xprev ? 1 : 0)) * D * sizeof(double),
+                                       hipMemcpyHostToDevice, s));
+  }
+  TrialCands tc;
+  tc.pool = d_pool; tc.M = M; tc.shifts = shifts; tc.extra = d_extra; tc.xprev = h_xprev ? xprev : nullptr;
+  tc.E_rows = E_rows; tc.E = E; tc.D = D;
+  const KernParams p = make_kern_params(m->kernel_id, m->theta);
+  if (screen_fp32) {
+    // the trials in batches of <= 8 (bounds the partial sums: 8 x n_split x Mt doubles)
+    const int blocks_x = (int)((Mt + SCR_T * SCR_CPT - 1) / (SCR_T * SCR_CPT));
+    for (int t0 = 0; t0 < T; t0 += 8) {
+      const int nb = (T - t0 < 8) ? (T - t0) : 8;
+      int n_split = (2048 + blocks_x * nb - 1) / (blocks_x * nb);
+      if (n_split > 16) n_split = 16;
+      if (n_split > (m->N + SCR_RJ - 1) / SCR_RJ) n_split = (m->N + SCR_RJ - 1) / SCR_RJ;
+      if (n_split < 1) n_split = 1;
+      const int rows_per_split = (m->N + n_split - 1) / n_split;
+      n_split = (m->N + rows_per_split - 1) / rows_per_split;
+      double* part = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_PART, (size_t)nb * n_split * Mt * sizeof(double));
+      if (!part) return (int)hipErrorOutOfMemory;
+      TrialCands tb = tc;
+      tb.shifts = shifts + (size_t)t0 * D;
+      const int extra_trial = (t0 == 0 && E > 0) ? 0 : -1;     // only the job's trial 0 sees the extra points
+      switch (m->kernel_id) {
+        case PPBO_KERNEL_SE: launch_screen<PPBO_KERNEL_SE>(m, p, tb, nb, rows_per_split, n_split, part, extra_trial, s); break;
+        case PPBO_KERNEL_RQ: launch_screen<PPBO_KERNEL_RQ>(m, p, tb, nb, rows_per_split, n_split, part, extra_trial, s); break;
+        default: launch_screen<PPBO_KERNEL_CAMPHOR>(m, p, tb, nb, rows_per_split, n_split, part, extra_trial, s); break;
+      }
+      screen_sum_kernel<<<dim3((unsigned)((Mt + 255) / 256), nb), 256, 0, s>>>(part, n_split, Mt, M, extra_trial, mu + (size_t)t0 * Mt);
+      PPBO_LAUNCH_CHECK(ctx);
+    }
+  } else {
+    // fp64 screening: every trial's candidates written out as rows and scored by ppbo_predict (mean only), exactly
+    // what the one-trial entry does with the rows ppbo_shift_points leaves
+    double* rows = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH_ROWS, (size_t)Mt * D * sizeof(double));
+    if (!rows) return (int)hipErrorOutOfMemory;
+    ppbo_model mean_only = *m;
+    mean_only.d_G = nullptr;
+    for (int t = 0; t < T; ++t) {
+      const long long nt = M + (t == 0 ? E : 0);
+      trial_rows_kernel<<<(unsigned)((nt * D + 255) / 256), 256, 0, s>>>(tc, t, rows);
+      PPBO_LAUNCH_CHECK(ctx);
+      if (int rc = ppbo_predict(ctx, &mean_only, rows, nt, PPBO_SCORE_MEAN, 0.0, mu + (size_t)t * Mt, nullptr, nullptr, nullptr,
+                                nullptr, stream))
+        return rc;
+      if (nt < Mt) {
+        // absent slots: -inf (0xFFF0000000000000 is not a byte pattern: a tiny fill kernel)
+        fill_kernel<<<(unsigned)((Mt - nt + 255) / 256), 256, 0, s>>>(mu + (size_t)t * Mt + nt, Mt - nt, -INFINITY);
+      }
+    }
+  }
+  group_max_kernel<<<dim3((Tg + 255) / 256, T), 256, 0, s>>>(mu, Mt, G, Tg, gval, gidx);
+  {
+    const size_t sel_lds = (size_t)Tg * (1 + D) * sizeof(double);
+    if (sel_lds > 64 * 1024) ppbo_lds_limit(ctx, (const void*)select_starts_kernel, 150 * 1024);
+    select_starts_kernel<<<T, 1024, sel_lds, s>>>(gval, gidx, Tg, nullptr, D, K, sep * sep, starts, counts, tc);
+  }
+  PPBO_LAUNCH_CHECK(ctx);
+  switch (m->kernel_id) {
+    case PPBO_KERNEL_SE: if (int rc = launch_mean_ascent<PPBO_KERNEL_SE>(ctx, m, p, starts, counts, T * K, iters, tol, d_x, d_mu, nullptr, s, K)) return rc; break;
+    case PPBO_KERNEL_RQ: if (int rc = launch_mean_ascent<PPBO_KERNEL_RQ>(ctx, m, p, starts, counts, T * K, iters, tol, d_x, d_mu, nullptr, s, K)) return rc; break;
+    default: if (int rc = launch_mean_ascent<PPBO_KERNEL_CAMPHOR>(ctx, m, p, starts, counts, T * K, iters, tol, d_x, d_mu, nullptr, s, K)) return rc; break;
+  }
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
 
 extern "C" int ppbo_rff_search(ppbo_ctx* ctx, const double* d_cand, int64_t M, int D, const double* d_W, int F,
                                const double* d_b, double sigma_f, const double* d_omega, int K, double sep, int iters,
@@ -553,7 +818,7 @@ extern "C" int ppbo_rff_search(ppbo_ctx* ctx, const double* d_cand, int64_t M, i
   {
     const size_t sel_lds = (size_t)T * (1 + D) * sizeof(double);
     if (sel_lds > 64 * 1024) ppbo_lds_limit(ctx, (const void*)select_starts_kernel, 150 * 1024);
-    select_starts_kernel<<<1, 1024, sel_lds, s>>>(gval, gidx, T, d_cand, D, K, sep * sep, starts, count);
+    select_starts_kernel<<<1, 1024, sel_lds, s>>>(gval, gidx, T, d_cand, D, K, sep * sep, starts, count, TrialCands{});
   }
   if (int rc = launch_rff_ascent(ctx, d_W, F, D, d_b, d_omega, std::sqrt(2.0 * sigma_f * sigma_f / (double)F), starts, count, K,
                                  iters, tol, d_x, d_val, s))

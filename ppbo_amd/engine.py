@@ -477,6 +477,41 @@ class Engine:
         n = found.value
         return xs[:n].cpu().numpy(), mus[:n].cpu().numpy()
 
+    def mean_search_multi(self, post: Posterior, pool, shifts, extra=None, xprev=None, K=32, sep=0.05, iters=100, tol=1e-9,
+                          screen_fp32=True):
+        """All trials of one mu_star call in one enqueue (ppbo_mean_search_multi): trial t searches frac(pool + shifts[t]);
+        trial 0 also the rows of `extra` ("design": the posterior's own design points, nothing is copied) and the point
+        `xprev`.  Returns the device tensors x[T, K, D], mu[T, K] (mu = -inf where a trial found fewer than K starts);
+        nothing synchronises."""
+        pool = self.dev(pool)
+        M, D = pool.shape
+        sh = np.ascontiguousarray(np.atleast_2d(np.asarray(shifts, dtype=np.float64)))
+        T = sh.shape[0]
+        if sh.shape[1] != D:
+            raise ValueError("mean_search_multi: shifts must be [T, D]")
+        E, ex_ptr = 0, None
+        if isinstance(extra, str):
+            if extra != "design":
+                raise ValueError("mean_search_multi: extra is an array of points or the string 'design'")
+            E = post.X.shape[0]
+        elif extra is not None:
+            extra = self.dev(extra)
+            E, ex_ptr = extra.shape[0], extra
+        xp = None
+        if xprev is not None:
+            xp = np.ascontiguousarray(np.asarray(xprev, dtype=np.float64).reshape(-1))
+            if xp.size != D:
+                raise ValueError("mean_search_multi: xprev must have D entries")
+        md = self._model(post, False)
+        xs, mus = self.empty(T, K, D), self.empty(T, K)
+        dp = C.POINTER(C.c_double)
+        rc = self.lib.ppbo_mean_search_multi(self.ctx, C.byref(md), _ptr(pool), M, sh.ctypes.data_as(dp), T, _ptr(ex_ptr), E,
+                                             xp.ctypes.data_as(dp) if xp is not None else None, int(K), float(sep),
+                                             int(iters), float(tol), int(bool(screen_fp32)), _ptr(xs), _ptr(mus),
+                                             self._stream())
+        self._check(rc, "ppbo_mean_search_multi")
+        return xs, mus
+
     def mean_ascent(self, post: Posterior, starts, iters=100, tol=1e-9):
         starts = self.dev(starts)
         K, D = starts.shape

@@ -46,6 +46,10 @@ class GPModel:
         self.n_appends = 0           # bordered updates of Sigma^-1 actually performed (ppbo_pd_inverse_append)
         self.n_full_inversions = 0   # full potrf + trtri + GEMM inversions
         self.fMAP_restart_on_stall = False   # opt-in: refit from a fresh prior draw when the trust region stalls
+        # mu_star ranks its 65536 candidates per trial by a posterior mean whose kernel values are evaluated in fp32
+        # (ppbo_mean_search_multi, screen_fp32): the ranking only picks the ascents' starts, every reported value comes
+        # from the fp64 ascent.  False: ranked by the fp64 mean (0.3 ms more per trial at C3).
+        self.mustar_screen_fp32 = True
         # "whitened": L-BFGS in z = L^-1 f finished by the trust region (ppbo_fit_fmap_whitened; O(N^2) per iteration; the
         # reference's optimum wherever T has one -- at sigma << sigma_f T has several local maxima and every local method,
         # SciPy's included, picks its own: DESIGN 5); anything else: the exact Newton trust region on f alone, which
@@ -671,41 +675,24 @@ class GPModel:
         D, N = self.D, self.N
         post = self._mean_post()
         pool = self._candidate_pool()
-        M = pool.shape[0]
-        work = torch.empty((M + N + 1, D), dtype=torch.float64, device=self.eng.device)
-        work[M:M + N].copy_(self._dX)                                  # the design points themselves
-        work[M + N].copy_(self.eng.dev(self.xstar if self.xstar is not None else self.X[0]))
-        # The trials are independent, and after its scoring pass a trial is a latency-bound chain (one workgroup picks
-        # the starts, ASCENT_STARTS workgroups climb): each trial gets a stream and a ctx of its own (the pairs the
-        # concurrent fits use), so the chains of one run beside the scoring of the next (3 trials at C3: 2.7 -> 2.3 ms; ten
-        # trials at C2: 0.43 -> 0.26 ms per trial).
-        # Everything is read back together: one synchronisation for the searches, one for the winners' gradient check.
-        main = torch.cuda.current_stream(self.eng.device)
-        side = self._side_engines(min(trials - 1, 2)) if trials > 1 else []      # three lanes: more do not add overlap
-        lanes = [(self.eng, main)] + side
+        # ALL trials in one enqueue (ppbo_mean_search_multi): each sees the resident pool through its own rotation, formed
+        # on the fly; one screening launch, one thinning launch, one start-selection launch (a workgroup per trial), one
+        # ascent launch of trials x ASCENT_STARTS workgroups.  (Rounds 3-4 ran one ppbo_mean_search per trial on three
+        # stream / ctx lanes: 3 trials at C3 2.0-2.3 ms, their kernels mostly serialised.)
+        # The design points (where f_MAP's maxima sit) and the previous x* join the first trial only: they would claim
+        # the same ASCENT_STARTS basins in every trial and leave the uniform candidates' basins unexplored.
+        shifts = np.stack([np.random.uniform(0.0, 1.0, D) for _ in range(trials)]) if trials > 0 else np.zeros((0, D))
+        xprev = np.asarray(self.xstar if self.xstar is not None else self.X[0], dtype=float).reshape(D)
         queued = []
-        for t in range(trials):
-            shift = np.random.uniform(0.0, 1.0, D)
-            eng_t, st_t = lanes[t % len(lanes)]
-            if 0 < t < len(lanes):
-                st_t.wait_stream(main)                                 # the pool, the posterior, `work` are ready
-            with torch.cuda.stream(st_t):
-                w_t = work if t == 0 else torch.empty((M, D), dtype=torch.float64, device=self.eng.device)
-                eng_t.shift_points(pool, shift, out=w_t[:M])
-                # the design points (where f_MAP's maxima sit) and the previous x* join the first trial only: they would
-                # claim the same ASCENT_STARTS basins in every trial and leave the uniform candidates' basins unexplored
-                queued.append(eng_t.mean_search(post, w_t, K=ASCENT_STARTS, sep=5e-2, iters=ASCENT_ITERS, tol=1e-9,
-                                                sync=False))
-        for _, st_k in side:
-            main.wait_stream(st_k)
-        for t in range(trials):
-            if t % len(lanes):
-                for r in queued[t]:
-                    r.record_stream(main)                              # produced on the trial's stream, read on this one
-        found, winners = [], []
+        for t0 in range(0, trials, 64):                                # the entry takes up to 64 trials
+            xs_d, mu_d = self.eng.mean_search_multi(post, pool, shifts[t0:t0 + 64], "design" if t0 == 0 else None,
+                                                    xprev if t0 == 0 else None, K=ASCENT_STARTS, sep=5e-2,
+                                                    iters=ASCENT_ITERS, tol=1e-9, screen_fp32=self.mustar_screen_fp32)
+            queued.append((xs_d, mu_d))
+        found, winners, winner_mu = [], [], {}
         if queued:
-            all_x = torch.stack([q[0] for q in queued]).cpu().numpy()            # [trials, K, D]
-            all_v = torch.stack([q[1] for q in queued]).cpu().numpy()            # [trials, K], -inf = no start
+            all_x = torch.cat([q[0] for q in queued]).cpu().numpy()              # [trials, K, D]
+            all_v = torch.cat([q[1] for q in queued]).cpu().numpy()              # [trials, K], -inf = no start
             per_trial = []
             for t in range(trials):
                 ok = np.isfinite(all_v[t])
@@ -717,15 +704,20 @@ class GPModel:
                 # the ascent stops on |projected gradient| * step < 1e-9; the quasi-Newton polish (a device round
                 # trip per function value) is only worth its milliseconds when a winner is NOT yet stationary
                 wx = np.stack([per_trial[t][0][b] for t, b in winners])
-                _, gw = self.eng.mean_grad(post, wx)
-                gw = gw.cpu().numpy()
-                for (t, b), gb in zip(winners, gw):
+                mw, gw = self.eng.mean_grad(post, wx)
+                mg = torch.cat([mw.reshape(-1, 1), gw], dim=1).cpu().numpy()       # one read-back: mu | grad per winner
+                for (t, b), row in zip(winners, mg):
                     xs, vals = per_trial[t]
+                    gb = row[1:]
                     pg = np.where(((xs[b] <= 0.0) & (gb < 0.0)) | ((xs[b] >= 1.0) & (gb > 0.0)), 0.0, gb)
                     if np.abs(pg).max() > POLISH_GRAD_TOL * max(abs(vals[b]), 1e-300):
                         xp, vp = self._polish(xs[b])
                         if vp >= vals[b]:
                             xs[b], vals[b] = xp, vp
+                    else:
+                        # mu_pred at this point, already on the host (the same K*' alpha in fp64 by mean_grad_kernel): if it
+                        # ends up as x*, mustar needs no further device round trip
+                        winner_mu[xs[b].tobytes()] = float(row[0])
             for xs, vals in per_trial:
                 found.extend(zip(vals.tolist(), xs))
         if not found:                 # no finite mean anywhere (cannot happen with a fitted model): keep the old x*
@@ -746,4 +738,5 @@ class GPModel:
                 keep.append(i)
                 struck |= d2[i] <= 1e-2
         xstars_local = P[keep].reshape(-1, D)
-        return xstar.reshape(D,), self.mu_pred(xstar), xstars_local
+        mustar = winner_mu.get(xstar.tobytes())
+        return xstar.reshape(D,), (self.mu_pred(xstar) if mustar is None else mustar), xstars_local

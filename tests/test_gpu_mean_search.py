@@ -182,3 +182,50 @@ def test_searches_in_every_dimension_bucket(eng, D, kernel):
         assert np.abs(orc.rff_score(xr, W, b, th[2], om) - vr).max() <= 1e-9 * np.abs(vr).max() + 1e-13
         assert vr.max() >= raw.max() - 1e-12
         assert vr.max() >= orc.rff_score(rng.random((20000, D)), W, b, th[2], om).max() - 1e-12
+
+
+@pytest.mark.parametrize("name", ["smoke", "rq", "cam_small", "c2", "c3"])
+@pytest.mark.parametrize("fp32", [False, True])
+def test_mean_search_multi_all_trials_in_one_enqueue(eng, golden, name, fp32):
+    """ppbo_mean_search_multi: T trials, each over its own rotation of the resident pool (+ the design points in trial
+    0), one ascent launch for all of them.  With the fp64 screening every trial must return exactly what
+    ppbo_mean_search returns on the rows ppbo_shift_points writes out (same candidates, same ranking, same ascent);
+    with the fp32 screening the starts may differ where two candidates tie to 1e-6, so the properties are checked:
+    every value is the posterior mean at its point, every point is (projected-)stationary, the best of a trial is at
+    least the best fp64 candidate value up to the screening's resolution, and rows without a start carry -inf."""
+    g = golden(name)
+    post = _post(eng, g)
+    D = int(g["D"])
+    rng = np.random.default_rng(11)
+    M, T, K = 4096, 3, 16
+    pool = rng.random((M, D))
+    shifts = rng.random((T, D))
+    extra, xprev = g["X"][:40], rng.random(D)
+    xs, mus = eng.mean_search_multi(post, pool, shifts, extra, xprev, K=K, sep=0.05, iters=100, tol=1e-9, screen_fp32=fp32)
+    xs, mus = host(xs), host(mus)
+    assert xs.shape == (T, K, D) and mus.shape == (T, K)
+    for t in range(T):
+        cand = host(eng.shift_points(eng.dev(pool), shifts[t]))
+        if t == 0:
+            cand = np.concatenate([cand, extra, xprev[None, :]])
+        ok = np.isfinite(mus[t])
+        assert ok.any() and np.all(mus[t][~ok] == -np.inf) and np.all(ok[:ok.sum()])       # found starts come first
+        mu_c = host(eng.predict(post, cand, want_var=False, want_best=False)["mu"])
+        mu1, g1 = eng.mean_grad(post, xs[t][ok])
+        assert np.abs(host(mu1) - mus[t][ok]).max() <= 1e-9 * np.abs(host(mu1)).max() + 1e-14
+        assert np.all((xs[t][ok] >= 0) & (xs[t][ok] <= 1))
+        if fp32:
+            assert mus[t][ok].max() >= mu_c.max() - 1e-5 * np.abs(mu_c).max()
+        else:
+            x1, m1 = eng.mean_search(post, cand, K=K, sep=0.05, iters=100, tol=1e-9)
+            assert len(m1) == ok.sum() and np.array_equal(m1, mus[t][ok]) and np.array_equal(x1, xs[t][ok])
+    # extra = "design": the posterior's own design points, straight from the model (no copy)
+    xd, md = eng.mean_search_multi(post, pool, shifts[:1], "design", None, K=K, screen_fp32=fp32)
+    xe, me = eng.mean_search_multi(post, pool, shifts[:1], g["X"], None, K=K, screen_fp32=fp32)
+    assert np.array_equal(host(xd), host(xe)) and np.array_equal(host(md), host(me))
+    # no extra points, one trial, more starts than survivors can supply
+    xs1, mus1 = eng.mean_search_multi(post, pool[:50], shifts[:1], None, None, K=64, sep=0.2, screen_fp32=fp32)
+    n = int(np.isfinite(host(mus1)[0]).sum())
+    assert 1 <= n < 64
+    with pytest.raises(ValueError):
+        eng.mean_search_multi(post, pool, shifts[:, :-1] if D > 1 else np.zeros((1, D + 1)))

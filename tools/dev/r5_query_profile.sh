@@ -31,5 +31,12 @@ for acq in ('EI-EXT','EI-VARMAX'):
                 a=agg.setdefault(nm,[0,0.0]); a[0]+=1; a[1]+=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
             for k,(n,d) in sorted(agg.items(), key=lambda kv:-kv[1][1]):
                 fo.write(f"{n:6d} {d:10.1f} us  {k}\n")
+            prev=None
+            for r in p:
+                st=int(r['Start_Timestamp']); en=int(r['End_Timestamp'])
+                if prev is not None and st-prev>15000:
+                    nm=r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','').split('(')[0].split('<')[0][-40:]
+                    fo.write(f"   gap {(st-prev)/1e3:7.1f} us before {nm} at {(st-t0)/1e3:8.1f} us\n")
+                prev=en
 PY
 rm -rf $OUT/tr_*
