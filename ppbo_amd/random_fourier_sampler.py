@@ -44,6 +44,20 @@ class Hsampler:
         # the model's resident uniform candidate pool (GPModel._candidate_pool: drawn once per model, rotated per use),
         # shared instead of drawing and uploading 65536 x D fresh uniforms per sampler (4 ms of a 13 ms cycle at D = 20)
         self._pool_of = getattr(gp_model, "_candidate_pool", None)
+        # device copies of W, b and X, made once per ARRAY OBJECT (assigning a new array refreshes them; the basis is 655 KB
+        # at F = 4096, D = 20, and every projection / search used to upload it again)
+        self._dcache = {}
+        dX = getattr(gp_model, "_dX", None)
+        if dX is not None and tuple(dX.shape) == tuple(np.shape(self.X)) and dX.device == self.eng.device:
+            self._dcache["X"] = (self.X, dX)
+
+    def _dev(self, name):
+        arr = getattr(self, name)
+        hit = self._dcache.get(name)
+        if hit is None or hit[0] is not arr:
+            hit = (arr, self.eng.dev(np.asarray(arr, dtype=float).ravel() if name == "b" else arr))
+            self._dcache[name] = hit
+        return hit[1]
 
     # ---- basis -----------------------------------------------------------------
     def generate_basis(self):
@@ -68,7 +82,7 @@ class Hsampler:
         raise NotImplementedError
 
     def update_phi_X(self):
-        self._dPhi = self.eng.rff_project(self.X, self.W, self.b.ravel(), self.theta[2])
+        self._dPhi = self.eng.rff_project(self._dev("X"), self._dev("W"), self._dev("b"), self.theta[2])
         self._phi_X = None
 
     @property
@@ -171,7 +185,7 @@ class Hsampler:
     # ---- maximiser of one posterior sample --------------------------------------------
     def score_candidates(self, Xc, omega):
         """phi(x)^T omega for many candidates on the device; returns (scores, best value, best index)."""
-        sc, bv, bi = self.eng.rff_score(Xc, self.W, self.b.ravel(), self.theta[2], omega)
+        sc, bv, bi = self.eng.rff_score(Xc, self._dev("W"), self._dev("b"), self.theta[2], omega)
         return sc.cpu().numpy(), bv, bi
 
     def return_xstar(self, omega):
@@ -198,7 +212,7 @@ class Hsampler:
         work[M:].copy_(self.eng.dev(near))
         # 100 Barzilai-Borwein iterations per start: the winning start is stationary after ~50 (tests/probes/
         # rff_ascent_scale.py: the same maximum at 50, 100 and 200), the cap only bounds the starts that keep bouncing
-        xs, vals = self.eng.rff_search(work, self.W, self.b.ravel(), self.theta[2], omega, K=RFF_STARTS, iters=100)
+        xs, vals = self.eng.rff_search(work, self._dev("W"), self._dev("b"), self.theta[2], omega, K=RFF_STARTS, iters=100)
         if self.verbose:
             print("Optimization of f_approx took " + str(time.time() - start) + " seconds.")
         if len(vals) == 0 or not np.isfinite(vals).any():
@@ -209,7 +223,7 @@ class Hsampler:
         x_ref = np.array(x_ref, dtype=float)
         grid = np.tile(x_ref, (4096, 1))
         grid[:, dim - 1] = np.linspace(0, 1, 4096)
-        _, _, bi = self.eng.rff_score(grid, self.W, self.b.ravel(), self.theta[2], omega, want_score=False)
+        _, _, bi = self.eng.rff_score(grid, self._dev("W"), self._dev("b"), self.theta[2], omega, want_score=False)
         return grid[bi]
 
     def sample_xstar(self):
