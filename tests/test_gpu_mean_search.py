@@ -229,3 +229,47 @@ def test_mean_search_multi_all_trials_in_one_enqueue(eng, golden, name, fp32):
     assert 1 <= n < 64
     with pytest.raises(ValueError):
         eng.mean_search_multi(post, pool, shifts[:, :-1] if D > 1 else np.zeros((1, D + 1)))
+
+
+def test_mean_search_multi_twenty_trials(eng, golden):
+    """The last iteration's 20 trials (src/gp_model.py:128-129) go through the screening pass in batches of eight; the
+    extra points belong to the job's trial 0 only, whatever the batch.  With the fp64 screening trial t of the 20-trial
+    call is bit for bit the one-trial call with the same shift; with the fp32 screening every trial still returns
+    stationary points whose values are the posterior mean there."""
+    g = golden("c2")
+    post = _post(eng, g)
+    D = int(g["D"])
+    rng = np.random.default_rng(5)
+    M, T, K = 2048, 20, 8
+    pool, shifts = rng.random((M, D)), rng.random((T, D))
+    xs, mus = eng.mean_search_multi(post, pool, shifts, "design", g["X"][0], K=K, screen_fp32=False)
+    xs, mus = host(xs), host(mus)
+    for t in (0, 7, 8, 15, 16, 19):
+        x1, m1 = eng.mean_search_multi(post, pool, shifts[t:t + 1], "design" if t == 0 else None, g["X"][0] if t == 0 else None,
+                                       K=K, screen_fp32=False)
+        assert np.array_equal(host(x1)[0], xs[t]) and np.array_equal(host(m1)[0], mus[t]), t
+    xf, mf = eng.mean_search_multi(post, pool, shifts, "design", g["X"][0], K=K, screen_fp32=True)
+    xf, mf = host(xf), host(mf)
+    for t in range(T):
+        ok = np.isfinite(mf[t])
+        assert ok.any()
+        mu1, _ = eng.mean_grad(post, xf[t][ok])
+        assert np.abs(host(mu1) - mf[t][ok]).max() <= 1e-9 * np.abs(host(mu1)).max() + 1e-14
+        # the two screenings find the same best maximum of the trial (to the ascents' own stopping tolerance)
+        assert abs(mf[t][ok].max() - mus[t][np.isfinite(mus[t])].max()) <= 1e-6 * abs(mus[t][np.isfinite(mus[t])].max())
+
+
+def test_mu_star_last_iteration_trials(golden):
+    """GPModel.mu_star with the reference's last-iteration budget (20 trials) is one enqueue and at least as good as 3."""
+    from test_gpu_dropin import _model
+    g = golden("c2")
+    gp, _ = _model(g)
+    gp.turn_initialization_off()
+    np.random.seed(4)
+    gp.update_model()
+    np.random.seed(7)
+    x3, m3, loc3 = gp.mu_star(mustar_finding_trials=3)
+    np.random.seed(7)
+    x20, m20, loc20 = gp.mu_star(mustar_finding_trials=20)
+    assert m20 >= m3 - 1e-9 * abs(m3) and len(loc20) >= len(loc3) - 2 and np.all((x20 >= 0) & (x20 <= 1))
+    assert abs(gp.mu_pred(x20) - m20) <= 1e-9 * abs(m20)
