@@ -141,7 +141,9 @@ def per_query_breakdown(torch, cfg="c2", reps=5):
       update_model_fit   the default update (one prior-draw start) = ONE ppbo_gp_fit call: Sigma, factor, inverse,
                          whitened f_MAP search, posterior (src/gp_model.py:91-117, without mu_star)
       fit_incremental    the same after ONE appended query with GPModel(incremental=True) (bordered factor, warm start)
-      mu_star            ONE trial of the device-resident search (the reference's default is 3 per iteration)
+      mu_star            per trial of the device-resident search (4 trials in one ppbo_mean_search_multi enqueue / 4;
+                         the reference's default is 3 per iteration)
+      update_model       GPModel.update_model() as the loop calls it: the fit + 3 mu_star trials
       next_query_*       every strategy family of src/acquisition.py:9-65: EI-EXT-FAST (D lines), EI-EXT (50 D lines),
                          EI / EXR (joint searches, BO_maxiter = 20), EI-VARMAX (50 D lines + the x search)
       hsampler_cycle     Hsampler(gp, F): basis, Phi(X), omega_MAP, one posterior sample and its maximiser
@@ -184,6 +186,8 @@ def per_query_breakdown(torch, cfg="c2", reps=5):
     gp.mu_star(mustar_finding_trials=1)
     out["mu_star_ms_per_trial"] = med(lambda: gp.mu_star(mustar_finding_trials=4)) / 4.0
     gp.xstar, gp.mustar, gp.xstars_local = gp.mu_star()
+    # the whole update of a query as the loop calls it: the fit + the reference's default 3 mu_star trials
+    out["update_model_ms"] = med(lambda: gp.update_model())
     for acq, key in (("EI-EXT-FAST", "next_query_EI_EXT_FAST_ms"), ("EI-EXT", "next_query_EI_EXT_ms"),
                      ("EI", "next_query_EI_search_ms"), ("EXR", "next_query_EXR_search_ms"),
                      ("EI-VARMAX", "next_query_EI_VARMAX_ms")):
