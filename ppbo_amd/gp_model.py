@@ -50,6 +50,7 @@ class GPModel:
         # (ppbo_mean_search_multi, screen_fp32): the ranking only picks the ascents' starts, every reported value comes
         # from the fp64 ascent.  False: ranked by the fp64 mean (0.3 ms more per trial at C3).
         self.mustar_screen_fp32 = True
+        self.polish_log = {"device_reascents": 0, "scipy_polishes": 0}    # how often mu_star's winners needed more than the ascent
         # "whitened": L-BFGS in z = L^-1 f finished by the trust region (ppbo_fit_fmap_whitened; O(N^2) per iteration; the
         # reference's optimum wherever T has one -- at sigma << sigma_f T has several local maxima and every local method,
         # SciPy's included, picks its own: DESIGN 5); anything else: the exact Newton trust region on f alone, which
@@ -706,18 +707,38 @@ class GPModel:
                 wx = np.stack([per_trial[t][0][b] for t, b in winners])
                 mw, gw = self.eng.mean_grad(post, wx)
                 mg = torch.cat([mw.reshape(-1, 1), gw], dim=1).cpu().numpy()       # one read-back: mu | grad per winner
-                for (t, b), row in zip(winners, mg):
+                def stationary(x, gb, v):
+                    pg = np.where(((x <= 0.0) & (gb < 0.0)) | ((x >= 1.0) & (gb > 0.0)), 0.0, gb)
+                    return np.abs(pg).max() <= POLISH_GRAD_TOL * max(abs(v), 1e-300)
+                todo = []
+                for k, ((t, b), row) in enumerate(zip(winners, mg)):
                     xs, vals = per_trial[t]
-                    gb = row[1:]
-                    pg = np.where(((xs[b] <= 0.0) & (gb < 0.0)) | ((xs[b] >= 1.0) & (gb > 0.0)), 0.0, gb)
-                    if np.abs(pg).max() > POLISH_GRAD_TOL * max(abs(vals[b]), 1e-300):
-                        xp, vp = self._polish(xs[b])
-                        if vp >= vals[b]:
-                            xs[b], vals[b] = xp, vp
-                    else:
+                    if stationary(xs[b], row[1:], vals[b]):
                         # mu_pred at this point, already on the host (the same K*' alpha in fp64 by mean_grad_kernel): if it
                         # ends up as x*, mustar needs no further device round trip
                         winner_mu[xs[b].tobytes()] = float(row[0])
+                    else:
+                        todo.append((t, b))
+                if todo:
+                    # winners the 100-evaluation ascent left short of stationarity: ONE more device ascent for all of them
+                    # (four times the budget, a tighter step tolerance) before anything goes through SciPy -- the
+                    # quasi-Newton polish costs a device round trip per function value
+                    self.polish_log["device_reascents"] += len(todo)
+                    p0 = np.stack([per_trial[t][0][b] for t, b in todo])
+                    xa, ma, _ = self.eng.mean_ascent(post, p0, iters=4 * ASCENT_ITERS, tol=1e-12)
+                    ma2, ga = self.eng.mean_grad(post, xa)
+                    xa, rows = xa.cpu().numpy(), torch.cat([ma2.reshape(-1, 1), ga], dim=1).cpu().numpy()
+                    for (t, b), xk, row in zip(todo, xa, rows):
+                        xs, vals = per_trial[t]
+                        if row[0] >= vals[b]:
+                            xs[b], vals[b] = xk, float(row[0])
+                        if stationary(xs[b], row[1:], vals[b]) and row[0] >= vals[b]:
+                            winner_mu[xs[b].tobytes()] = float(row[0])
+                            continue
+                        self.polish_log["scipy_polishes"] += 1
+                        xp, vp = self._polish(xs[b])
+                        if vp >= vals[b]:
+                            xs[b], vals[b] = xp, vp
             for xs, vals in per_trial:
                 found.extend(zip(vals.tolist(), xs))
         if not found:                 # no finite mean anywhere (cannot happen with a fitted model): keep the old x*
