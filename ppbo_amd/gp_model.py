@@ -510,7 +510,7 @@ class GPModel:
         self._post_mean = Posterior(self.kernel.__name__, tuple(float(t) for t in self.theta), self.m, self._dX, alpha,
                                     None, None, None)
 
-    def _fit_fused(self):
+    def _fit_fused(self, defer_posterior=False):
         """The default update (one prior-draw start, whitened search) as ONE library call: ppbo_gp_fit builds Sigma,
         its factor and inverse, runs the search from the prior draw L z0 -- z0 from the global NumPy stream, exactly the
         numbers _draw_prior would have consumed -- and the posterior state, with one host wait instead of one per
@@ -523,8 +523,12 @@ class GPModel:
             print("MAP-estimation begins...")
         start = time.time()
         z0 = np.random.standard_normal(self.N)
+        # defer_posterior (update_model, N >= 1024): the call ends with f_MAP; Lambda_MAP / the posterior factor -- a
+        # latency-bound chain of 0.9 ms at N = 2048 that mu_star does not need (it reads alpha only) -- then run on a second
+        # ctx and stream BESIDE mu_star (_start_posterior / _finish_posterior): update_model at C3 3.9 -> 3.5 ms
         r = self.eng.gp_fit(self._dX, self.theta, self.kernel.__name__, self.m, z0, shrink=self.COVARIANCE_SHRINKAGE,
-                            gtol=self.fMAP_gtol, start_is_whitened=True, want_Sigma=True, want_posterior=True)
+                            gtol=self.fMAP_gtol, start_is_whitened=True, want_Sigma=True,
+                            want_posterior=not defer_posterior)
         th = tuple(float(t) for t in self.theta)
         self._dSigma, self._dSigma_inv, self._dL, self._dLinv = r["Sigma"], r["Sigma_inv"], r["L"], None
         self._sinv_state = (self.X.copy(), th, 0)
@@ -551,7 +555,10 @@ class GPModel:
             print("... this took " + str(time.time() - start) + " seconds.")
             print("Current theta is: " + str(self.theta) + " (Acq. = " + str(self.xi_acquisition_function) + ")")
             print("Updating Lambda_MAP and posterior covariance...")
-        if r["post"] is not None:
+        if defer_posterior:
+            self._refresh_mean_state(r["fMAP"])            # alpha: all mu_star needs
+            self._start_posterior(r["fMAP"])
+        elif r["post"] is not None:
             self._post = self._post_mean = r["post"]
             self._invalidate("Lambda_MAP", "P", "Pinv")
         else:
@@ -559,12 +566,56 @@ class GPModel:
             self._refresh_mean_state(r["fMAP"])
         return True
 
+    def _start_posterior(self, fmap_dev):
+        """Lambda_MAP, alpha and the posterior factor G (ppbo_posterior) on a side ctx / stream, in a host thread of its
+        own (the call ends with a host wait; ctypes releases the GIL): the caller goes on with mu_star and collects the
+        result with _finish_posterior."""
+        import threading
+        import torch
+        (side, stream), = self._side_engines(1)
+        box = {}
+        main = torch.cuda.current_stream(self.eng.device)
+
+        def work():
+            try:
+                stream.wait_stream(main)               # f_MAP, Sigma^-1 were produced on the caller's stream
+                with torch.cuda.stream(stream):
+                    box["post"] = side.posterior(self._dX, self.theta, self.kernel.__name__, self._dSigma_inv, fmap_dev,
+                                                 self.m, want_P=False)
+                    stream.synchronize()
+            except Exception as e:                      # noqa: BLE001  (looked at in _finish_posterior)
+                box["err"] = e
+
+        th = threading.Thread(target=work)
+        th.start()
+        self._pending_posterior = (th, box)
+
+    def _finish_posterior(self):
+        pend = self.__dict__.pop("_pending_posterior", None)
+        if pend is None:
+            return
+        import torch
+        th, box = pend
+        th.join()
+        err = box.get("err")
+        if isinstance(err, NotPositiveDefinite):
+            print("---!!!--- Posterior covariance matrix is not PSD ---!!!---")   # gp_model.py:119, keep the old one
+            return
+        if err is not None:
+            raise err
+        post = box["post"]
+        main = torch.cuda.current_stream(self.eng.device)
+        for t in (post.alpha, post.lam_diag, post.lam_off, post.G):
+            t.record_stream(main)                       # allocated on the side stream, consumed on the caller's from here on
+        self._post = self._post_mean = post
+        self._invalidate("Lambda_MAP", "P", "Pinv")
+
     # ------------------------------------------------------------------ orchestration (gp_model.py:87-132)
     def update_model(self, optimize_theta=False):
         if self.theta is None:
             self.set_theta()
         init_skip = self.initialization_running and self.skip_computations_during_initialization
-        fused = (not init_skip) and (not optimize_theta) and self._fit_fused()
+        fused = (not init_skip) and (not optimize_theta) and self._fit_fused(defer_posterior=self.N >= 1024)
         if not fused:
             self.update_Sigma(self.theta)
             self.update_Sigma_inv(self.theta)
@@ -598,14 +649,17 @@ class GPModel:
         if self.verbose:
             print("Computing mu_star and x_star ...")
         start = time.time()
-        if init_skip and not self.skip_xstaroptimization_during_initialization:
-            self.xstar, self.mustar, self.xstars_local = self.mu_star(mustar_finding_trials=1)
-        elif self.initialization_running and self.skip_xstaroptimization_during_initialization:
-            pass
-        elif self.last_iteration:
-            self.xstar, self.mustar, self.xstars_local = self.mu_star(mustar_finding_trials=20)
-        else:
-            self.xstar, self.mustar, self.xstars_local = self.mu_star()
+        try:
+            if init_skip and not self.skip_xstaroptimization_during_initialization:
+                self.xstar, self.mustar, self.xstars_local = self.mu_star(mustar_finding_trials=1)
+            elif self.initialization_running and self.skip_xstaroptimization_during_initialization:
+                pass
+            elif self.last_iteration:
+                self.xstar, self.mustar, self.xstars_local = self.mu_star(mustar_finding_trials=20)
+            else:
+                self.xstar, self.mustar, self.xstars_local = self.mu_star()
+        finally:
+            self._finish_posterior()                   # the posterior factor that ran beside mu_star (if any)
         if self.verbose:
             print("... this took " + str(time.time() - start) + " seconds.")
 
