@@ -637,13 +637,17 @@ class GPModel:
                 if self.verbose:
                     print("Updating Lambda_MAP and posterior covariance...")
                 start = time.time()
-                try:
-                    self._post = self.eng.posterior(self._dX, self.theta, self.kernel.__name__, self._dSigma_inv,
-                                                    self.eng.dev(self.fMAP), self.m, want_P=False)
-                    self._post_mean = self._post
-                    self._invalidate("Lambda_MAP", "P", "Pinv")
-                except NotPositiveDefinite:
-                    print("---!!!--- Posterior covariance matrix is not PSD ---!!!---")   # gp_model.py:119, keep the old one
+                if self.N >= 1024 and not self.last_iteration:
+                    # beside mu_star, as after the fused fit (the restarts of the last iteration occupy the side contexts)
+                    self._start_posterior(self.eng.dev(self.fMAP))
+                else:
+                    try:
+                        self._post = self.eng.posterior(self._dX, self.theta, self.kernel.__name__, self._dSigma_inv,
+                                                        self.eng.dev(self.fMAP), self.m, want_P=False)
+                        self._post_mean = self._post
+                        self._invalidate("Lambda_MAP", "P", "Pinv")
+                    except NotPositiveDefinite:
+                        print("---!!!--- Posterior covariance matrix is not PSD ---!!!---")   # gp_model.py:119, keep the old one
                 if self.verbose:
                     print("... this took " + str(time.time() - start) + " seconds.")
         if self.verbose:
