@@ -768,7 +768,9 @@ int check_model(ppbo_ctx* ctx, const ppbo_model* m) {
 int pick_split(int M, int n_q) {
   // enough (block, split) pairs to give every SIMD several wavefronts
   const int blocks = (M + KS_THREADS * KS_CPT - 1) / (KS_THREADS * KS_CPT);
-  int want = (2048 + blocks - 1) / blocks;
+  // ~1024 workgroups: from 16384 candidates on a workgroup then covers 64+ rows (round 5 sweep at N = 2048, K* launch:
+  // 16384 candidates 0.112 -> 0.099 ms against a target of 2048; 8192 and 65536 candidates unchanged at 0.064 / 0.305)
+  int want = (1024 + blocks - 1) / blocks;
   if (want > n_q) want = n_q;
   if (want > 64) want = 64;
   if (want < 1) want = 1;
