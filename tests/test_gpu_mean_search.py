@@ -171,6 +171,20 @@ def test_searches_in_every_dimension_bucket(eng, D, kernel):
     assert vals.max() >= mu_c.max() - 1e-12 * max(1.0, np.abs(mu_c).max())
     dense, _ = orc.mean_grad(rng.random((20000, D)), X, th, alpha, kernel)
     assert vals.max() >= dense.max() - 1e-12
+    # the same through the all-trials entry: its fp32 screening kernel is compiled per padded dimension too
+    pool, shifts = rng.random((6000, D)), rng.random((2, D))
+    for fp32 in (True, False):
+        xm, vm = eng.mean_search_multi(post, pool, shifts, "design", X[0], K=16, sep=0.05, iters=100, tol=1e-9, screen_fp32=fp32)
+        xm, vm = host(xm), host(vm)
+        for t in range(2):
+            ok = np.isfinite(vm[t])
+            assert ok.any() and np.all((xm[t][ok] >= 0) & (xm[t][ok] <= 1))
+            mu2, _ = orc.mean_grad(xm[t][ok], X, th, alpha, kernel)
+            assert np.abs(mu2 - vm[t][ok]).max() <= 1e-9 * np.abs(mu2).max() + 1e-14
+            ct = (pool + shifts[t]) % 1.0
+            ct = np.vstack([ct, X, X[:1]]) if t == 0 else ct
+            mu_t, _ = orc.mean_grad(ct, X, th, alpha, kernel)
+            assert vm[t][ok].max() >= mu_t.max() - (1e-5 if fp32 else 1e-12) * max(1.0, np.abs(mu_t).max())
     if kernel == "SE_kernel":
         F = 96
         W = np.random.default_rng(3).standard_normal((F, D)) / th[1]
