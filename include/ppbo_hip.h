@@ -251,7 +251,10 @@ int ppbo_posterior(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fMA
  * by EI/varmax (src/acquisition.py:72-81,170-178).
  * d_Xc[M,D] candidates in [0,1]^D.  Outputs (NULL to skip): d_mu[M], d_var[M],
  * d_score[M]; h_best_val / h_best_idx = max score and its FIRST index
- * (np.argmax semantics).  d_G may be NULL when only the mean is wanted. */
+ * (np.argmax semantics).  d_G may be NULL when only the mean is wanted.
+ * Any N = n_q (m + 1), any m, any M: where N is not a multiple of the 128-row tile / 16-deep chunk of the variance
+ * contraction (m = 25, the reference's default) the call works on a zero-framed copy of G in a ctx workspace (from
+ * 2048 candidates on; ~3 N^2 x 8 bytes moved per call), and K* is always padded to whole 128-candidate tiles. */
 typedef struct ppbo_model {
   int kernel_id, N, D, m;
   double theta[3];
