@@ -328,6 +328,7 @@ def test_update_model_posterior_beside_mu_star_changes_nothing(golden, capsys):
     g = golden("c3")
     gp, _ = _model(g)
     gp.turn_initialization_off()
+    gp._candidate_pool()                                # drawn once per model: both runs below then take the same numbers
     np.random.seed(5)
     gp.update_model()                                   # deferred (N = 2048)
     assert "_pending_posterior" not in gp.__dict__
