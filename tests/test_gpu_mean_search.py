@@ -287,3 +287,32 @@ def test_mu_star_last_iteration_trials(golden):
     x20, m20, loc20 = gp.mu_star(mustar_finding_trials=20)
     assert m20 >= m3 - 1e-9 * abs(m3) and len(loc20) >= len(loc3) - 2 and np.all((x20 >= 0) & (x20 <= 1))
     assert abs(gp.mu_pred(x20) - m20) <= 1e-9 * abs(m20)
+
+
+def test_mean_search_multi_rejects_bad_arguments(eng, golden):
+    """Argument errors come back as status codes (RuntimeError through the binding), never as a crash."""
+    import ctypes as C
+    from ppbo_amd.engine import _ptr
+    g = golden("smoke")
+    post = _post(eng, g)
+    D = int(g["D"])
+    rng = np.random.default_rng(0)
+    pool = eng.dev(rng.random((256, D)))
+    with pytest.raises(RuntimeError):
+        eng.mean_search_multi(post, pool, rng.random((65, D)))                       # more than 64 trials per call
+    with pytest.raises(RuntimeError):
+        eng.mean_search_multi(post, pool, rng.random((1, D)), K=2000)                # K > 1024
+    with pytest.raises(ValueError):
+        eng.mean_search_multi(post, pool, rng.random((1, D)), xprev=np.zeros(D + 1))
+    with pytest.raises(ValueError):
+        eng.mean_search_multi(post, pool, rng.random((1, D)), extra="something")
+    # d_extra = NULL stands for the model's own design points: any other row count is refused
+    md = eng._model(post, False)
+    xs, mus = eng.empty(1, 4, D), eng.empty(1, 4)
+    sh = np.ascontiguousarray(rng.random((1, D)))
+    rc = eng.lib.ppbo_mean_search_multi(eng.ctx, C.byref(md), _ptr(pool), 256, sh.ctypes.data_as(C.POINTER(C.c_double)), 1,
+                                        None, 7, None, 4, 0.05, 10, 1e-9, 1, _ptr(xs), _ptr(mus), eng._stream())
+    assert rc != 0
+    # and the ctx is fine afterwards
+    x, v = eng.mean_search_multi(post, pool, sh, "design", None, K=4)
+    assert np.isfinite(host(v)).any()
