@@ -36,6 +36,14 @@ extern "C" {
 #define PPBO_ABI_VERSION 5
 #define PPBO_ERR_NOT_PD 1001
 
+/* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY dynamic symbols
+ * (tests/test_abi.py checks `nm -D --defined-only` against this header). */
+#if defined(__GNUC__) || defined(__clang__)
+#define PPBO_API __attribute__((visibility("default")))
+#else
+#define PPBO_API
+#endif
+
 typedef struct ppbo_ctx ppbo_ctx;
 
 /* kernel ids: src/kernels.py:19 (SE), :27 (RQ, alpha=2), :36 (camphor-copper, D must be 6) */
@@ -48,45 +56,45 @@ enum {
   PPBO_SCORE_VARIANCE = 2      /* sigma^2(x): G=1 form of varmax, src/acquisition.py:170-178 */
 };
 
-int ppbo_abi_version(void);
-int ppbo_ctx_create(int device, ppbo_ctx** out);
-int ppbo_ctx_destroy(ppbo_ctx* ctx);
+PPBO_API int ppbo_abi_version(void);
+PPBO_API int ppbo_ctx_create(int device, ppbo_ctx** out);
+PPBO_API int ppbo_ctx_destroy(ppbo_ctx* ctx);
 /* copies the last error text of this ctx into buf (NUL terminated) */
-int ppbo_last_error(ppbo_ctx* ctx, char* buf, size_t n);
+PPBO_API int ppbo_last_error(ppbo_ctx* ctx, char* buf, size_t n);
 
 /* ---- per-kernel event timing (the reference only prints time.time() deltas when verbose,
  * src/gp_model.py:110-132).  When enabled, the named hot kernels are bracketed
  * by hipEvents on the caller's stream; ppbo_profile_read synchronises those events and
  * returns the accumulated duration and launch count since the last reset.
  * names: "gram", "kstar", "quadform", "score", "rff_project", "rff_score", "potrf". */
-int ppbo_profile_enable(ppbo_ctx* ctx, int on);
-int ppbo_profile_reset(ppbo_ctx* ctx);
-int ppbo_profile_read(ppbo_ctx* ctx, const char* name, double* h_total_ms, int* h_count);
+PPBO_API int ppbo_profile_enable(ppbo_ctx* ctx, int on);
+PPBO_API int ppbo_profile_reset(ppbo_ctx* ctx);
+PPBO_API int ppbo_profile_read(ppbo_ctx* ctx, const char* name, double* h_total_ms, int* h_count);
 
 /* ---- K1: Gram matrix with the closed-form shrinkage --------------------
  * replaces GPModel.create_Gramian (src/gp_model.py:147-151) =
  * kernel(X,X,theta) (src/kernels.py:19-53) + regularize_covariance
  * (src/misc.py:71-88; SVD round trip == identity, shrink == (1-s)K + s tr(K)/N I).
  * d_X[N,D] -> d_Sigma[N,N]. */
-int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D,
+PPBO_API int ppbo_gram(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D,
               const double h_theta[3], double shrink, double* d_Sigma, void* stream);
 
 /* a-3 as its own operator: regularize_covariance(X, reg_level, pos_diag=True, jitter) of src/misc.py:71-88 applied
  * IN PLACE to any device matrix d_K[N, ldk] (gp_model.py:150 calls it on the raw Gramian; ppbo_gram fuses the same
  * closed form): negative diagonal entries -> jitter when pos_diag != 0, then K <- (1 - reg_level) K + reg_level tr(K)/N I
  * (sklearn.covariance.shrunk_covariance).  The SVD round trip of misc.py:79-80 is the identity and is not executed. */
-int ppbo_regularize_covariance(ppbo_ctx* ctx, double* d_K, int N, int ldk, double reg_level, int pos_diag,
+PPBO_API int ppbo_regularize_covariance(ppbo_ctx* ctx, double* d_K, int N, int ldk, double reg_level, int pos_diag,
                                double jitter, void* stream);
 
 /* measurement probe, not part of the path: a write-only pass over d_S[N,N] (32 x 128 tiles, 16-byte write-through
  * stores, the fastest store shape tools/store_floor.hip found): the ceiling of ANY Gram kernel at that N on this
  * chip.  bench.py times it beside ppbo_gram (`write_only_floor_*`) instead of quoting constants. */
-int ppbo_store_floor(ppbo_ctx* ctx, double* d_S, int N, void* stream);
+PPBO_API int ppbo_store_floor(ppbo_ctx* ctx, double* d_S, int N, void* stream);
 
 /* ---- K2: raw cross-covariance ------------------------------------------
  * replaces GPModel.create_Gramian_nonsquare (src/gp_model.py:153-155).
  * d_X1[n1,D], d_X2[n2,D] -> d_K[n1,n2] (row stride ldk >= n2). */
-int ppbo_cross_cov(ppbo_ctx* ctx, int kernel_id, const double* d_X1, int n1,
+PPBO_API int ppbo_cross_cov(ppbo_ctx* ctx, int kernel_id, const double* d_X1, int n1,
                    const double* d_X2, int n2, int D, const double h_theta[3],
                    double* d_K, int ldk, void* stream);
 
@@ -96,16 +104,16 @@ int ppbo_cross_cov(ppbo_ctx* ctx, int kernel_id, const double* d_X1, int n1,
  *   (LAPACK convention); return value PPBO_ERR_NOT_PD in that case.
  * ppbo_pd_inverse replaces misc.pd_inverse (src/misc.py:96-100): d_Ainv = A^-1
  *   (full symmetric matrix written). */
-int ppbo_potrf(ppbo_ctx* ctx, double* d_A, int N, int lda, int* h_info, void* stream);
-int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int* h_info, void* stream);
+PPBO_API int ppbo_potrf(ppbo_ctx* ctx, double* d_A, int N, int lda, int* h_info, void* stream);
+PPBO_API int ppbo_pd_inverse(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, int* h_info, void* stream);
 
 /* ppbo_pd_inverse that also hands out L^-1 (A = L L^T, full matrix, zeros above the diagonal); d_Linv may be NULL */
-int ppbo_pd_inverse_factors(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, double* d_Linv, int* h_info,
+PPBO_API int ppbo_pd_inverse_factors(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, double* d_Linv, int* h_info,
                             void* stream);
 /* ... and, when d_L is not NULL, the Cholesky factor itself: d_L[N,N], lower triangle = L, the strict upper triangle
  * is a copy of A's and is never read by this library.  L is what ppbo_fit_fmap_whitened iterates with, and
  * L z (ppbo_dgemv, lower = 1) is the prior draw of src/gp_model.py:374,381.  d_L and d_Linv may each be NULL. */
-int ppbo_pd_inverse_ex(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, double* d_L, double* d_Linv,
+PPBO_API int ppbo_pd_inverse_ex(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, double* d_L, double* d_Linv,
                        int* h_info, void* stream);
 
 /* ---- f-4: the inverse after one query has been appended --------------------------------
@@ -120,12 +128,12 @@ int ppbo_pd_inverse_ex(ppbo_ctx* ctx, const double* d_A, int N, double* d_Ainv, 
  * d_A[N,N] is the new matrix; d_A11inv / d_L11inv [N1,N1] (row stride N1) the inverse of its leading block and of
  * that block's Cholesky factor (from ppbo_pd_inverse_factors or a previous append); d_Ainv / d_Linv [N,N] the
  * results.  PPBO_ERR_NOT_PD (info = failing column of A) when S is not positive definite. */
-int ppbo_pd_inverse_append(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, const double* d_L11inv,
+PPBO_API int ppbo_pd_inverse_append(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, const double* d_L11inv,
                            int N1, double* d_Ainv, double* d_Linv, int* h_info, void* stream);
 /* ... that also borders the factor itself: d_L11[N1,N1] (row stride N1, lower triangle = factor of the leading block,
  * as ppbo_pd_inverse_ex or a previous call returned it) -> d_L[N,N] = [[L11, 0], [Y^T, L22]], so the appended design
  * can go straight into ppbo_fit_fmap_whitened.  d_L11 and d_L are both NULL or both given. */
-int ppbo_pd_inverse_append_ex(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, const double* d_L11inv,
+PPBO_API int ppbo_pd_inverse_append_ex(ppbo_ctx* ctx, const double* d_A, int N, const double* d_A11inv, const double* d_L11inv,
                               const double* d_L11, int N1, double* d_Ainv, double* d_Linv, double* d_L, int* h_info,
                               void* stream);
 
@@ -137,7 +145,7 @@ int ppbo_pd_inverse_append_ex(ppbo_ctx* ctx, const double* d_A, int N, const dou
  * Outputs (any may be NULL): d_Tlik[1] = -(1/m) sum_q sum_j Phi(Delta_qj/sqrt2);
  * d_beta[N]; d_lam_diag[N], d_lam_off[N] = Lambda in star-graph form
  * (off[j] = Lambda[obs(j), j] for pseudo rows, 0 on observation rows). */
-int ppbo_laplace_terms(ppbo_ctx* ctx, const double* d_f, int N, int m, double sigma,
+PPBO_API int ppbo_laplace_terms(ppbo_ctx* ctx, const double* d_f, int N, int m, double sigma,
                        double* d_Tlik, double* d_beta, double* d_lam_diag,
                        double* d_lam_off, void* stream);
 
@@ -145,7 +153,7 @@ int ppbo_laplace_terms(ppbo_ctx* ctx, const double* d_f, int N, int m, double si
  * d_out[q] for the n_q = N/(m+1) queries, order 0 = sum_j Phi(Delta_qj/sqrt2) (closed form of the Gauss-Hermite
  * integral at :192), 1 = sum_j var2_normal_pdf(Delta_qj), 2 = sum_j -Delta_qj/2 var2_normal_pdf(Delta_qj);
  * any other order is an argument error (the reference prints and returns None). */
-int ppbo_sum_phi(ppbo_ctx* ctx, const double* d_f, int N, int m, double sigma, int order, double* d_out,
+PPBO_API int ppbo_sum_phi(ppbo_ctx* ctx, const double* d_f, int N, int m, double sigma, int order, double* d_out,
                  void* stream);
 
 /* ---- a-8: f_MAP by trust-region Newton -----------------------------------
@@ -181,7 +189,7 @@ typedef struct ppbo_fit_stats {
                          * start, 5 budget spent, 6 the factor does not exist (Sigma not positive definite: ppbo_gp_fit
                          * returns PPBO_ERR_NOT_PD); -1 when the pre-phase did not run */
 } ppbo_fit_stats;
-int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double sigma,
+PPBO_API int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double sigma,
                   const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
                   ppbo_fit_stats* h_stats, void* stream);
 
@@ -196,7 +204,7 @@ int ppbo_fit_fmap(ppbo_ctx* ctx, const double* d_Sigma_inv, int N, int m, double
  * ppbo_fit_fmap from the point reached, so the result satisfies exactly what ppbo_fit_fmap's does.
  * Same optimum as the reference on every golden fixture; the PATH (and hence, on a multi-modal posterior, which
  * local maximum is found) is not SciPy's. */
-int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m,
+PPBO_API int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_Sigma_inv, int N, int m,
                            double sigma, const double* d_f_init, const ppbo_fit_opts* opts, double* d_fMAP,
                            ppbo_fit_stats* h_stats, void* stream);
 
@@ -223,13 +231,13 @@ int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, const doub
  * Returns PPBO_ERR_NOT_PD with *h_info = 1 when Sigma is not positive definite, *h_info = 2 when Sigma^-1 - Lambda_MAP
  * is not (f_MAP and the factors of Sigma are valid then; the reference prints its '---!!!---' line and keeps the
  * previous posterior, src/gp_model.py:118-120). */
-int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, const double theta[3], double shrink,
+PPBO_API int ppbo_gp_fit(ppbo_ctx* ctx, int kernel_id, const double* d_X, int N, int D, const double theta[3], double shrink,
                 int m, const double* d_f_init, const ppbo_fit_opts* opts, double* d_Sigma, double* d_Sigma_inv,
                 double* d_L, double* d_Linv, double* d_fMAP, double* d_alpha, double* d_lam_diag, double* d_lam_off,
                 double* d_G, ppbo_fit_stats* h_stats, int* h_info, void* stream);
 
 /* T(f) and grad T(f) for a given f (src/gp_model.py:221-240); h_T / d_grad may be NULL */
-int ppbo_T_and_grad(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_f, int N, int m,
+PPBO_API int ppbo_T_and_grad(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_f, int N, int m,
                     double sigma, double* h_T, double* d_grad, void* stream);
 
 /* ---- posterior state for prediction ---------------------------------------
@@ -241,7 +249,7 @@ int ppbo_T_and_grad(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_f,
  * d_P (optional, may be NULL) = posterior_covariance = B^-1 (src/gp_model.py:117).
  * Returns PPBO_ERR_NOT_PD when B is not positive definite (the reference prints
  * '---!!!--- Posterior covariance matrix is not PSD ---!!!---' and continues). */
-int ppbo_posterior(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fMAP, int N, int m,
+PPBO_API int ppbo_posterior(ppbo_ctx* ctx, const double* d_Sigma_inv, const double* d_fMAP, int N, int m,
                    double sigma, double* d_alpha, double* d_lam_diag, double* d_lam_off,
                    double* d_G, double* d_P, int* h_info, void* stream);
 
@@ -270,7 +278,7 @@ typedef struct ppbo_model {
                              * differences, all accumulation fp64 -- BASELINE config 5's "fp32 tolerance" variant;
                              * its error against the fp64 path is REPORTED (bench.py), it does not meet 1e-5 */
 } ppbo_model;
-int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
+PPBO_API int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
                  int score_kind, double mustar, double* d_mu, double* d_var, double* d_score,
                  double* h_best_val, int64_t* h_best_idx, void* stream);
 
@@ -279,12 +287,12 @@ int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int
  * a double, exact below 2^53) -- (NaN, -1) when no candidate has a non-NaN score -- i.e. exactly the 16-byte record
  * that ppbo_argmax_allgather_record / torch.distributed all-gather (written by the one-workgroup argmax launch that
  * ends the pass). */
-int ppbo_predict_record(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
+PPBO_API int ppbo_predict_record(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
                         int score_kind, double mustar, int64_t index_offset, double* d_record, void* stream);
 
 /* full predictive covariance of small sets (the G=70 line grid of EI):
  * d_cov[M,M] = (1-s)K(Xc,Xc) + s sigma_f^2 I - K*^T A K*  (src/gp_model.py:447-450) */
-int ppbo_predict_cov(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int M,
+PPBO_API int ppbo_predict_cov(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int M,
                      double shrink, double* d_mu, double* d_cov, void* stream);
 
 /* ---- f-2: posterior mean with its analytic gradient ----------------------------
@@ -293,7 +301,7 @@ int ppbo_predict_cov(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc,
  * differential evolution; the drop-in refines the best candidates of the batched search by a
  * multi-start ascent on these gradients instead.  Only kernel_id, N, D, theta, d_X, d_alpha of the
  * model are read. */
-int ppbo_mean_grad(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
+PPBO_API int ppbo_mean_grad(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
                    double* d_mu, double* d_grad, void* stream);
 
 /* ---- f-2, device-resident: the maximiser of the posterior mean ---------------------------------------
@@ -305,11 +313,11 @@ int ppbo_mean_grad(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, i
  * synchronises).  ppbo_mean_ascent is the last stage alone, from caller-chosen starts (d_iters[K] optional).
  * ppbo_shift_points: d_out = frac(d_in + h_shift[D]) row-wise -- a rotation of a RESIDENT uniform candidate pool,
  * so that repeated searches see fresh candidates without regenerating and uploading M x D numbers. */
-int ppbo_mean_search(ppbo_ctx* ctx, const ppbo_model* model, const double* d_cand, int64_t M, int K, double sep,
+PPBO_API int ppbo_mean_search(ppbo_ctx* ctx, const ppbo_model* model, const double* d_cand, int64_t M, int K, double sep,
                      int iters, double tol, double* d_x, double* d_mu, int* h_found, void* stream);
-int ppbo_mean_ascent(ppbo_ctx* ctx, const ppbo_model* model, const double* d_starts, int K, int iters, double tol,
+PPBO_API int ppbo_mean_ascent(ppbo_ctx* ctx, const ppbo_model* model, const double* d_starts, int K, int iters, double tol,
                      double* d_x, double* d_mu, int* d_iters, void* stream);
-int ppbo_shift_points(ppbo_ctx* ctx, const double* d_in, int64_t M, int D, const double* h_shift, double* d_out,
+PPBO_API int ppbo_shift_points(ppbo_ctx* ctx, const double* d_in, int64_t M, int D, const double* h_shift, double* d_out,
                       void* stream);
 
 /* ALL trials of one mu_star call in one enqueue (src/gp_model.py:415-437: `mustar_finding_trials` differential-evolution
@@ -322,7 +330,7 @@ int ppbo_shift_points(ppbo_ctx* ctx, const double* d_in, int64_t M, int D, const
  * v_exp_f32; accumulated in fp64; relative error ~1e-6) -- every reported value and point comes from the fp64 ascent;
  * 0: ranked by the fp64 mean of ppbo_predict, as ppbo_mean_search does (bit-identical results to T such calls).
  * d_x[T,K,D], d_mu[T,K]: the refined maxima per trial (rows that found no start: mu = -inf).  Nothing synchronises. */
-int ppbo_mean_search_multi(ppbo_ctx* ctx, const ppbo_model* model, const double* d_pool, int64_t M,
+PPBO_API int ppbo_mean_search_multi(ppbo_ctx* ctx, const ppbo_model* model, const double* d_pool, int64_t M,
                            const double* h_shifts, int T, const double* d_extra, int E_rows, const double* h_xprev,
                            int K, double sep, int iters, double tol, int screen_fp32, double* d_x, double* d_mu,
                            void* stream);
@@ -331,7 +339,7 @@ int ppbo_mean_search_multi(ppbo_ctx* ctx, const ppbo_model* model, const double*
  * replaces EI / varmax (src/acquisition.py:72-81, 170-178) for B lines of G points
  * with stored standard-normal draws d_z[S,G]: f = mu + chol(cov) z.
  * d_grid[B,G,D] -> d_ei[B], d_varmax[B] (either may be NULL). */
-int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, int B, int G,
+PPBO_API int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, int B, int G,
                   double shrink, const double* d_z, int S, double mustar, double jitter,
                   double* d_ei, double* d_varmax, void* stream);
 /* The same with the grid points formed ON THE DEVICE: line b is {alpha[g] * d_xi[b,:] + d_x[b,:]}, g < G -- what
@@ -340,7 +348,7 @@ int ppbo_line_acq(ppbo_ctx* ctx, const ppbo_model* model, const double* d_grid, 
  * src/acquisition.py:72-75).  d_alpha[G] when alpha_per_line == 0 (one abscissa vector shared by all lines: common
  * random numbers), d_alpha[B,G] otherwise.  Nothing of size B x G x D crosses the host boundary: (xi, x, alpha) are
  * B x (2 D + G) numbers (EI-EXT at D = 20: 1000 lines, 110 KB instead of an 11 MB grid built by 1000 Python calls). */
-int ppbo_line_acq_xi(ppbo_ctx* ctx, const ppbo_model* model, const double* d_xi, const double* d_x,
+PPBO_API int ppbo_line_acq_xi(ppbo_ctx* ctx, const ppbo_model* model, const double* d_xi, const double* d_x,
                      const double* d_alpha, int alpha_per_line, int B, int G, double shrink, const double* d_z, int S,
                      double mustar, double jitter, double* d_ei, double* d_varmax, void* stream);
 
@@ -349,7 +357,7 @@ int ppbo_line_acq_xi(ppbo_ctx* ctx, const ppbo_model* model, const double* d_xi,
  * (seed, index) (Philox-4x32-10 + Box-Muller), i.e. reproducible and independent of the launch geometry.  Replaces
  * the np.random.multivariate_normal / standard_normal draws of src/acquisition.py:76,174 where the caller does not
  * need NumPy's own stream (the batched searches; EI() / varmax() called with explicit draws keep the caller's z). */
-int ppbo_randn(ppbo_ctx* ctx, uint64_t seed, double* d_out, int64_t n, void* stream);
+PPBO_API int ppbo_randn(ppbo_ctx* ctx, uint64_t seed, double* d_out, int64_t n, void* stream);
 
 /* ---- K7/K8/K9: random Fourier features --------------------------------------
  * ppbo_rff_project replaces Hsampler.phiVec/update_phi_X
@@ -357,12 +365,12 @@ int ppbo_randn(ppbo_ctx* ctx, uint64_t seed, double* d_out, int64_t n, void* str
  * ppbo_rff_score replaces phi(x)^T omega (:166,170) batched over M candidates with
  *   an on-device argmax (Phi(Xc) never materialised).
  * ppbo_rff_terms replaces S, S_grad, diag(S_hessian) (:106-122); outputs may be NULL. */
-int ppbo_rff_project(ppbo_ctx* ctx, const double* d_X, int N, int D, const double* d_W, int F,
+PPBO_API int ppbo_rff_project(ppbo_ctx* ctx, const double* d_X, int N, int D, const double* d_W, int F,
                      const double* d_b, double sigma_f, double* d_Phi, void* stream);
-int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const double* d_W, int F,
+PPBO_API int ppbo_rff_score(ppbo_ctx* ctx, const double* d_Xc, int64_t M, int D, const double* d_W, int F,
                    const double* d_b, double sigma_f, const double* d_omega, double* d_score,
                    double* h_best_val, int64_t* h_best_idx, void* stream);
-int ppbo_rff_terms(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, double sigma,
+PPBO_API int ppbo_rff_terms(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, double sigma,
                    const double* d_omega, double* h_S, double* d_grad, double* d_hdiag, void* stream);
 
 /* Hsampler.update_omega_MAP (src/random_fourier_sampler.py:124-132): maximise S from the start vector in d_omega[F]
@@ -374,7 +382,7 @@ int ppbo_rff_terms(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, doub
  * iteration), the host only keeps a few iterations enqueued ahead of a host-mapped progress word and reads S, |grad S|
  * and the iteration count once, at the end.  d_omega is written on `stream` (ordered for later work on that stream).
  * Stops on |grad S| < gtol (h_gradnorm belongs to the point returned), maxiter, or a collapsed radius. */
-int ppbo_rff_omega_map(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, double sigma, double* d_omega,
+PPBO_API int ppbo_rff_omega_map(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, double sigma, double* d_omega,
                        int maxiter, double gtol, double* h_S, double* h_gradnorm, int* h_iterations, void* stream);
 
 /* the maximiser of ONE posterior sample phi(x)^T omega, device-resident: replaces Hsampler.return_xstar's 5-30
@@ -382,13 +390,13 @@ int ppbo_rff_omega_map(ppbo_ctx* ctx, const double* d_Phi, int F, int N, int m, 
  * (ppbo_rff_score), keeps the K best that are > sep apart and runs the whole projected Barzilai-Borwein ascent of
  * each inside one kernel with the analytic gradient -a sum_f omega_f sin(w_f.x + b_f) w_f (:51-53).
  * d_x[K,D] / d_val[K]: refined maxima (rows >= *h_found: value -inf). */
-int ppbo_rff_search(ppbo_ctx* ctx, const double* d_cand, int64_t M, int D, const double* d_W, int F,
+PPBO_API int ppbo_rff_search(ppbo_ctx* ctx, const double* d_cand, int64_t M, int D, const double* d_W, int F,
                     const double* d_b, double sigma_f, const double* d_omega, int K, double sep, int iters,
                     double tol, double* d_x, double* d_val, int* h_found, void* stream);
 
 /* ---- generic fp64 MFMA GEMM (exposed for tests and host-side composition) ----
  * C[M,N] = alpha op(A) op(B) + beta C.  transA/transB: 0 = as stored, 1 = transposed. */
-int ppbo_dgemm(ppbo_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha,
+PPBO_API int ppbo_dgemm(ppbo_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha,
                const double* d_A, int lda, const double* d_B, int ldb, double beta,
                double* d_C, int ldc, void* stream);
 
@@ -400,9 +408,9 @@ int ppbo_dgemm(ppbo_ctx* ctx, int transA, int transB, int M, int N, int K, doubl
  * *h_info = k>0 if u_kk == 0.
  * ppbo_laplace_logdet forms M = I + Sigma*Lambda (src/gp_model.py:301-302, plus sign as in the
  * reference) from the star-form Lambda and calls ppbo_lu_slogdet on it. */
-int ppbo_lu_slogdet(ppbo_ctx* ctx, double* d_A, int N, int lda, double* h_u_sign, double* h_u_logdet,
+PPBO_API int ppbo_lu_slogdet(ppbo_ctx* ctx, double* d_A, int N, int lda, double* h_u_sign, double* h_u_logdet,
                     int* h_info, void* stream);
-int ppbo_laplace_logdet(ppbo_ctx* ctx, const double* d_Sigma, const double* d_lam_diag,
+PPBO_API int ppbo_laplace_logdet(ppbo_ctx* ctx, const double* d_Sigma, const double* d_lam_diag,
                         const double* d_lam_off, int N, int m, double* h_u_sign, double* h_u_logdet,
                         int* h_info, void* stream);
 
@@ -415,32 +423,32 @@ int ppbo_laplace_logdet(ppbo_ctx* ctx, const double* d_Sigma, const double* d_la
  *   all:     ppbo_dist_init(ctx, id, rank, world)   (collective; the ctx's device is the rank's GPU)
  *   search:  ppbo_argmax_allgather(ctx, local_val, local_idx + shard_offset, &val, &idx, stream)
  * Return codes 2000 + ncclResult_t for RCCL failures. */
-int ppbo_dist_unique_id(ppbo_ctx* ctx, void* h_id128);
-int ppbo_dist_init(ppbo_ctx* ctx, const void* h_id128, int rank, int world);
-int ppbo_dist_destroy(ppbo_ctx* ctx);
-int ppbo_argmax_allgather(ppbo_ctx* ctx, double local_val, int64_t local_global_idx, double* h_best_val,
+PPBO_API int ppbo_dist_unique_id(ppbo_ctx* ctx, void* h_id128);
+PPBO_API int ppbo_dist_init(ppbo_ctx* ctx, const void* h_id128, int rank, int world);
+PPBO_API int ppbo_dist_destroy(ppbo_ctx* ctx);
+PPBO_API int ppbo_argmax_allgather(ppbo_ctx* ctx, double local_val, int64_t local_global_idx, double* h_best_val,
                           int64_t* h_best_idx, void* stream);
 /* the same exchange fed from DEVICE memory (d_record[2] as written by ppbo_predict_record): no host value is
  * uploaded first; all-gather, reduction and the 16-byte read-back run behind each other on `stream`. */
-int ppbo_argmax_allgather_record(ppbo_ctx* ctx, const double* d_record, double* h_best_val, int64_t* h_best_idx,
+PPBO_API int ppbo_argmax_allgather_record(ppbo_ctx* ctx, const double* d_record, double* h_best_val, int64_t* h_best_idx,
                                  void* stream);
 /* one whole sharded search step in ONE call: ppbo_predict_record on this rank's M rows (global row index =
  * index_offset + local row), ncclAllGather of the records, reduction, one 16-byte read-back, ONE host wait.
  * Every rank returns the job-wide (best score, global index).  Without ppbo_dist_init (a single-process search)
  * the collective is skipped.  Replaces the sequential search of mu_star (src/gp_model.py:415-437) over a sharded
  * candidate set; the reference itself is process-per-run (ppbo_numerical_main.py:192-193). */
-int ppbo_search_sharded(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
+PPBO_API int ppbo_search_sharded(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
                         double mustar, int64_t index_offset, double* h_best_val, int64_t* h_best_idx, void* stream);
 /* the reduction alone, for callers that run the all-gather themselves (torch.distributed in ppbo_amd/dist.py):
  * d_records[world][2] = (value, global index as a double) per rank, already gathered in device memory; one
  * single-wavefront kernel applies the rule above and ONE 16-byte record is copied back. */
-int ppbo_argmax_combine(ppbo_ctx* ctx, const double* d_records, int world, double* h_best_val, int64_t* h_best_idx,
+PPBO_API int ppbo_argmax_combine(ppbo_ctx* ctx, const double* d_records, int world, double* h_best_val, int64_t* h_best_idx,
                         void* stream);
 
 /* y = op(A) x for a square fp64 matrix; lower != 0 reads only the lower triangle (A is then
  * treated as lower-triangular).  Used for alpha = Sigma^-1 f_MAP (src/gp_model.py:445) and
  * prior draws L z (src/gp_model.py:374). */
-int ppbo_dgemv(ppbo_ctx* ctx, int trans, int lower, int N, const double* d_A, int lda,
+PPBO_API int ppbo_dgemv(ppbo_ctx* ctx, int trans, int lower, int N, const double* d_A, int lda,
                const double* d_x, double* d_y, void* stream);
 
 #ifdef __cplusplus

@@ -18,7 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppbo_hip.so")
 STAMP = os.path.join(HERE, ".libppbo_hip.stamp")
 SOURCES = ["capi.hip", "gram.hip", "gemm.hip", "linalg.hip", "fit.hip", "predict.hip", "meangrad.hip", "rff.hip", "lu.hip", "dist.hip"]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+         "-fvisibility=hidden"]   # the dynamic symbol table is include/ppbo_hip.h (PPBO_API), nothing else
 
 
 def _hipcc():
@@ -61,7 +62,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC",
+           "-Wl,--version-script=" + os.path.join(CSRC, "libppbo_hip.map"), "-o", LIB, *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")

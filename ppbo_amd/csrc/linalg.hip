@@ -1189,6 +1189,7 @@ int ppbo_apply_linv_async(ppbo_ctx* ctx, const double* d_Linv, int ldi, const do
   return ppbo_gemv_rect_async(ctx, d_Linv, split, split, ldi, d_tmp, nullptr, d_y, 1, 1, s);
 }
 
+namespace {
 // A[j][i] = A[i][j] for i > j: 32 x 32 tiles through LDS, one workgroup per tile of the lower triangle
 __global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ A, int N, int lda) {
   __shared__ double t[32][33];
@@ -1208,6 +1209,7 @@ __global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ 
     if (i < N && j < N && i > j) store_through(A + (size_t)j * lda + i, t[tx][r]);
   }
 }
+}  // namespace
 
 // d_Ainv = Linv^T Linv for a lower-triangular Linv: only the tiles of the lower triangle are computed (the K range of a
 // tile starts at its row), the upper triangle is their mirror image (exactly symmetric).  Up to N = 3072 the product runs on

@@ -32,6 +32,23 @@ def test_library_exports_every_declared_symbol():
     assert lib.ppbo_abi_version() == _lib.ABI_VERSION == 5
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """-fvisibility=hidden + the version script: the dynamic symbol table is the header's entry points and the HIP
+    toolchain's per-TU registration ids (__hip_cuid_*) -- no mangled internals, no device stubs, no libstdc++ weak symbols."""
+    import shutil
+    import subprocess
+    from ppbo_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from ppbo_amd.build import build
+        build(verbose=False)
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    exported = sorted(n for n in names if not n.startswith("__hip_"))
+    assert exported == header_symbols(), sorted(set(exported) ^ set(header_symbols()))
+    assert all(n.startswith("__hip_cuid_") for n in names if n.startswith("__hip_"))
+
+
 def test_no_gpu_means_loud_failure():
     import torch
     if torch.cuda.is_available():
