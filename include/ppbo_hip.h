@@ -223,8 +223,10 @@ PPBO_API int ppbo_fit_fmap_whitened(ppbo_ctx* ctx, const double* d_L, int ldl, c
  *     forms agree bit for bit for every start; without start_is_whitened, or below N = 1024, the rule is armed from
  *     the first evaluation.  Everything (both streams) is complete when the call returns.
  *   - a Sigma that is not positive definite ends the search before its first evaluation (the factorization's info word
- *     is read on the device by the search's first launch): the call returns at once, nothing runs on the half-factored
- *     matrix.
+ *     is read on the device by the search's first launch): the search performs no evaluation and the call returns
+ *     PPBO_ERR_NOT_PD without a posterior phase.  The inverse pipeline that was enqueued behind the factorization
+ *     (triangular inverse, Sigma^-1, the start product) still runs to completion on the half-factored matrix; its
+ *     outputs (d_Sigma_inv, d_L, d_Linv, d_fMAP) are undefined in that case.
  * Outputs (device, caller-owned): d_Sigma [N,N] (NULL to skip), d_Sigma_inv [N,N], d_L [N,N] (Cholesky factor of
  * Sigma, lower triangle valid), d_Linv [N,N] (NULL: kept in a workspace), d_fMAP [N], and -- all four or none --
  * d_alpha, d_lam_diag, d_lam_off [N], d_G [N,N] as ppbo_posterior defines them.

@@ -52,6 +52,26 @@ void* ppbo_pinned(ppbo_ctx* ctx, size_t bytes) {
   return p;
 }
 
+int ppbo_upload_async(ppbo_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return 0;
+  ppbo_ctx::UploadSlot& u = ctx->upload[ctx->upload_next++ & 3];
+  if (!u.ev) PPBO_HIP_CHECK(ctx, hipEventCreateWithFlags(&u.ev, hipEventDisableTiming));
+  if (u.used) PPBO_HIP_CHECK(ctx, hipEventSynchronize(u.ev));     // four uploads ago: long done in practice
+  if (u.bytes < bytes) {
+    if (u.p) (void)hipHostFree(u.p);
+    u.p = nullptr; u.bytes = 0;
+    const size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
+    if (hipHostMalloc(&u.p, want, hipHostMallocDefault) != hipSuccess)
+      return ppbo_set_error(ctx, (int)hipErrorOutOfMemory, "pinned upload slot: hipHostMalloc(%zu) failed", want);
+    u.bytes = want;
+  }
+  std::memcpy(u.p, h_src, bytes);
+  PPBO_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, u.p, bytes, hipMemcpyHostToDevice, s));
+  PPBO_HIP_CHECK(ctx, hipEventRecord(u.ev, s));
+  u.used = true;
+  return 0;
+}
+
 int ppbo_host_record(ppbo_ctx* ctx, PpboHostRecord* out) {
   if (!ctx->hostrec) {
     void* h = nullptr;
@@ -148,6 +168,10 @@ int ppbo_ctx_destroy(ppbo_ctx* ctx) {
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->hostrec) (void)hipHostFree(ctx->hostrec);
+  for (auto& u : ctx->upload) {
+    if (u.p) (void)hipHostFree(u.p);
+    if (u.ev) (void)hipEventDestroy(u.ev);
+  }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);

@@ -30,6 +30,11 @@ struct ppbo_ctx {
   size_t ws_bytes[WS_COUNT] = {};
   void* pinned = nullptr;  // small pinned host staging buffer
   size_t pinned_bytes = 0;
+  // ring of pinned upload slots for small host arguments that travel by hipMemcpyAsync (ppbo_upload_async): a slot is
+  // reused only after the event recorded behind its last copy has completed
+  struct UploadSlot { void* p = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool used = false; };
+  UploadSlot upload[4];
+  unsigned upload_next = 0;
   // optional per-kernel event timing
   bool profiling = false;
   enum { PF_GRAM = 0, PF_KSTAR, PF_QUADFORM, PF_SCORE, PF_RFF_PROJECT, PF_RFF_SCORE, PF_POTRF, PF_LINE_KSTAR, PF_LINE_Y, PF_LINE_COV, PF_LINE_MC, PF_COUNT };
@@ -133,6 +138,9 @@ int ppbo_set_error(ppbo_ctx* ctx, int code, const char* fmt, ...);
 // returns a device pointer of at least `bytes` (contents undefined); nullptr on failure
 void* ppbo_workspace(ppbo_ctx* ctx, int slot, size_t bytes);
 void* ppbo_pinned(ppbo_ctx* ctx, size_t bytes);
+// copies h_src (any host memory; consumed before the call returns) to d_dst through a pinned slot of the ctx, truly
+// asynchronously on `s`: neither blocks the host on the stream nor relies on how the runtime stages pageable memory
+int ppbo_upload_async(ppbo_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hipStream_t s);
 // raise a kernel's dynamic-LDS limit to `bytes` once per ctx (i.e. once per device)
 void ppbo_lds_limit(ppbo_ctx* ctx, const void* kernel_fn, int bytes);
 

@@ -37,10 +37,12 @@ __global__ __launch_bounds__(GC::NT, (GC::NT == 512) ? 4 : 2) void dgemm_kernel(
   if (g.lower_only && n0 > m0 + BM - 1) return;
   int kbeg = 0, kend = g.K;
   if (g.khi_mode == 1) {
-    // rounded up to the chunk depth: A (= G of a posterior, the only user of this mode) carries explicit zeros right of
-    // a row's last star, and a K range that is a whole number of chunks keeps the tile on the unguarded loop whatever
-    // the star size (m = 25, the reference's default: 26-row stars)
-    const int e = (((m0 + BM + g.tri_block - 1) / g.tri_block) * g.tri_block + BK - 1) & ~(BK - 1);
+    // tri_block > 1 (A = G of a posterior): rounded up to the chunk depth -- G carries explicit zeros right of a row's
+    // last star, and a K range that is a whole number of chunks keeps the tile on the unguarded loop whatever the star
+    // size (m = 25, the reference's default: 26-row stars).  tri_block == 1 (the triangular inverse's products on an
+    // Linv whose strict upper part is unwritten): NO round-up -- the K range must end at the triangle's edge
+    int e = ((m0 + BM + g.tri_block - 1) / g.tri_block) * g.tri_block;
+    if (g.tri_block > 1) e = (e + BK - 1) & ~(BK - 1);
     kend = e < g.K ? e : g.K;
   } else if (g.khi_mode == 2) {
     const int e = (m0 < n0 ? m0 : n0) + BM;

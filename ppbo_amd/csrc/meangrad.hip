@@ -722,15 +722,11 @@ extern "C" int ppbo_mean_search_multi(ppbo_ctx* ctx, const ppbo_model* m, const 
   double* starts = gval + (size_t)T * Tg;
   int* gidx = (int*)(starts + (size_t)T * K * D);
   int* counts = gidx + (size_t)T * Tg;
-  {
-    // the shifts and the previous x* leave the host in ONE copy (pageable memory: the runtime has consumed the buffer
-    // when hipMemcpyAsync returns)
-    std::vector<double> stage((size_t)(T + 1) * D);
-    std::memcpy(stage.data(), h_shifts, (size_t)T * D * sizeof(double));
-    if (h_xprev) std::memcpy(stage.data() + (size_t)T * D, h_xprev, (size_t)D * sizeof(double));
-    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(shifts, stage.data(), (size_t)(T + (h_xprev ? 1 : 0)) * D * sizeof(double),
-                                       hipMemcpyHostToDevice, s));
-  }
+  // the shifts and the previous x* leave the host through pinned upload slots of the ctx (ppbo_upload_async): the call
+  // has consumed h_shifts / h_xprev when it returns and never blocks on the stream
+  if (int rc = ppbo_upload_async(ctx, shifts, h_shifts, (size_t)T * D * sizeof(double), s)) return rc;
+  if (h_xprev)
+    if (int rc = ppbo_upload_async(ctx, xprev, h_xprev, (size_t)D * sizeof(double), s)) return rc;
   TrialCands tc;
   tc.pool = d_pool; tc.M = M; tc.shifts = shifts; tc.extra = d_extra; tc.xprev = h_xprev ? xprev : nullptr;
   tc.E_rows = E_rows; tc.E = E; tc.D = D;

@@ -485,6 +485,9 @@ class Engine:
         nothing synchronises."""
         pool = self.dev(pool)
         M, D = pool.shape
+        if D != post.X.shape[1]:
+            # the library strides pool, shifts and extra by the MODEL's D: a mismatch would read out of bounds on the device
+            raise ValueError(f"mean_search_multi: pool has {D} columns, the model {post.X.shape[1]}")
         sh = np.ascontiguousarray(np.atleast_2d(np.asarray(shifts, dtype=np.float64)))
         T = sh.shape[0]
         if sh.shape[1] != D:
@@ -496,6 +499,8 @@ class Engine:
             E = post.X.shape[0]
         elif extra is not None:
             extra = self.dev(extra)
+            if extra.dim() != 2 or extra.shape[1] != D:
+                raise ValueError("mean_search_multi: extra must be [E, D]")
             E, ex_ptr = extra.shape[0], extra
         xp = None
         if xprev is not None:

@@ -542,13 +542,26 @@ class GPModel:
                                  lbfgs_status=st["lbfgs_status"], converged=st["converged"], warm=False,
                                  seconds=time.time() - start))
         fm_host = r["fMAP"].cpu().numpy()
-        if not (np.isfinite(st["T"]) and st["lbfgs_status"] != 4 and np.all(np.isfinite(fm_host))):
-            # the start had no finite objective and the finisher did not recover one: what update_fMAP does when every
-            # trial ends that way -- the previous estimate (and the previous posterior) stay
+        if not (np.isfinite(st["T"]) and np.all(np.isfinite(fm_host))):
+            # neither the search nor the finisher behind it (lbfgs_status 4 = the start had no finite objective; the
+            # trust region may still have recovered one: then T and f_MAP ARE finite and the fit stands) produced a finite
+            # objective: what update_fMAP does when every trial ends that way -- the previous estimate stays.  Mean AND
+            # variance state are rebuilt from it at the CURRENT design, so that next_query never mixes a new mean with a
+            # posterior of another N
             print("---!!!--- f_MAP search produced no finite objective; keeping the previous f_MAP ---!!!---")
             if self.fMAP is None or len(self.fMAP) != self.N:
                 self.fMAP = np.zeros(self.N)
-            self._refresh_mean_state(self.eng.dev(self.fMAP))
+            kept = self.eng.dev(self.fMAP)
+            self._refresh_mean_state(kept)
+            try:
+                self._post = self._post_mean = self.eng.posterior(self._dX, self.theta, self.kernel.__name__,
+                                                                  self._dSigma_inv, kept, self.m, want_P=False)
+                self._invalidate("Lambda_MAP", "P", "Pinv")
+            except NotPositiveDefinite:
+                print("---!!!--- Posterior covariance matrix is not PSD ---!!!---")
+                if self._post is not None and self._post.X.shape[0] != self.N:
+                    self._post = None      # a posterior of another design: predictions of the variance raise instead
+                    self._invalidate("Lambda_MAP", "P", "Pinv")
             return True
         self.fMAP = fm_host
         if self.verbose:
@@ -576,9 +589,13 @@ class GPModel:
         box = {}
         main = torch.cuda.current_stream(self.eng.device)
 
+        # f_MAP and Sigma^-1 were produced on the caller's stream: the dependency is recorded HERE, in the calling thread,
+        # before mu_star enqueues anything on `main` -- recorded inside the worker it would land wherever `main` happens to
+        # be when that thread first runs, and the side stream would then wait for mu_star's launches as well
+        stream.wait_stream(main)
+
         def work():
             try:
-                stream.wait_stream(main)               # f_MAP, Sigma^-1 were produced on the caller's stream
                 with torch.cuda.stream(stream):
                     box["post"] = side.posterior(self._dX, self.theta, self.kernel.__name__, self._dSigma_inv, fmap_dev,
                                                  self.m, want_P=False)

@@ -319,7 +319,7 @@ def test_fmap_method_is_a_setting(golden):
         PPBO_settings(D=2, bounds=((0, 1),) * 2, xi_acquisition_function="PCD", fMAP_method="newton")
 
 
-def test_update_model_posterior_beside_mu_star_changes_nothing(golden, capsys):
+def test_update_model_posterior_beside_mu_star_changes_nothing(golden, capsys, monkeypatch):
     """From N = 1024 on update_model ends ppbo_gp_fit at f_MAP and forms Lambda_MAP / the posterior factor on a second ctx
     and stream BESIDE mu_star (which reads alpha only).  The model state afterwards is bit for bit the one of the fit
     that does everything in one call; a posterior precision that is not positive definite still prints the reference's
@@ -340,15 +340,20 @@ def test_update_model_posterior_beside_mu_star_changes_nothing(golden, capsys):
         assert np.array_equal(getattr(gp._post, k).cpu().numpy(), v), k
     gp.xstar, gp.mustar, gp.xstars_local = gp.mu_star()
     assert np.array_equal(gp.xstar, x_a) and gp.mustar == m_a
-    # not positive definite: a sigma so small that Lambda dominates Sigma^-1
-    old_G = gp._post.G
-    gp.theta = [1e-9, gp.theta[1], gp.theta[2]]
+    # not positive definite, deterministically: the side engine's posterior raises what ppbo_posterior
+    # reports for a Sigma^-1 - Lambda_MAP that is not PD; the deferred path must print the reference's line
+    # (src/gp_model.py:119), keep the previous posterior object and leave nothing pending
+    from ppbo_amd.engine import NotPositiveDefinite
+    old_post, old_G = gp._post, gp._post.G
+    (side, _stream), = gp._side_engines(1)
+
+    def not_pd(*a, **k):
+        raise NotPositiveDefinite("posterior precision not PD (test)")
+
+    monkeypatch.setattr(side, "posterior", not_pd)
     np.random.seed(6)
     capsys.readouterr()
-    try:
-        gp.update_model()
-    except Exception:                                   # noqa: BLE001  (a fit that fails outright is not what is tested here)
-        pytest.skip("the fit itself failed at this theta")
+    gp.update_model()
     out = capsys.readouterr().out
-    if "Posterior covariance matrix is not PSD" in out:
-        assert gp._post.G is old_G and "_pending_posterior" not in gp.__dict__
+    assert "Posterior covariance matrix is not PSD" in out
+    assert gp._post is old_post and gp._post.G is old_G and "_pending_posterior" not in gp.__dict__

@@ -306,6 +306,19 @@ def test_mean_search_multi_rejects_bad_arguments(eng, golden):
         eng.mean_search_multi(post, pool, rng.random((1, D)), xprev=np.zeros(D + 1))
     with pytest.raises(ValueError):
         eng.mean_search_multi(post, pool, rng.random((1, D)), extra="something")
+    # the library strides pool / shifts / extra by the model's D: a mismatch is refused before it can read out of bounds
+    with pytest.raises(ValueError):
+        eng.mean_search_multi(post, eng.dev(rng.random((256, D + 1))), rng.random((1, D + 1)))
+    with pytest.raises(ValueError):
+        eng.mean_search_multi(post, pool, rng.random((1, D)), extra=rng.random((8, D + 2)))
+    # many calls in a row reuse the pinned upload slots (four per ctx): same inputs, same outputs
+    sh4 = np.ascontiguousarray(rng.random((3, D)))
+    ref = None
+    for _ in range(9):
+        x, v = eng.mean_search_multi(post, pool, sh4, "design", np.full(D, 0.5), K=4)
+        cur = (host(x).copy(), host(v).copy())
+        assert ref is None or (np.array_equal(cur[0], ref[0]) and np.array_equal(cur[1], ref[1], equal_nan=True))
+        ref = cur
     # d_extra = NULL stands for the model's own design points: any other row count is refused
     md = eng._model(post, False)
     xs, mus = eng.empty(1, 4, D), eng.empty(1, 4)
