@@ -551,6 +551,7 @@ def main():
     qf_ms, qf_n = eng.profile_read("quadform")
     ks_ms, ks_n = eng.profile_read("kstar")
     sc_ms, sc_n = eng.profile_read("score")
+    fu_ms, fu_n = eng.profile_read("fused_score")
     eng.profile(False)
     # the other leg (every rank scoring --candidates rows of its own), same protocol, for the side key
     other_leg = None
@@ -671,12 +672,16 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = M_total * args.steps / elapsed
-        qf_avg_ms = qf_ms / max(qf_n, 1)
+        # models of up to ~1024 rows are scored by ONE launch (csrc/fused.hip: K* in LDS, contraction, score); the
+        # dominant kernel is then that launch, priced on the contraction's executed MFMA flops over its WHOLE duration
+        fused_path = fu_n > 0 and qf_n == 0
+        qf_avg_ms = (fu_ms / max(fu_n, 1)) if fused_path else qf_ms / max(qf_n, 1)
+        qf_launches = fu_n if fused_path else qf_n
         mblk = m + 1
         # algorithmic flops of the variance contraction per launch: 2 M N^2 (dense A);
         # executed: the block-triangular G form does M * sum_tiles 2*128*kend(tile) flops
         # one launch scores a chunk of <= 65536 candidates (ppbo_predict's chunk_cap); the average is over launches
-        M_launch = float(M) / max(1, -(-M // 65536))
+        M_launch = float(M) if fused_path else float(M) / max(1, -(-M // 65536))
         algo_flops = 2.0 * M_launch * N * N
         # executed: each wavefront owns 32 rows of a 128-row tile and stops at the end of their last star block
         # (equals SQ_INSTS_MFMA x 2048 of the rocprofv3 --pmc pass, profiles/)
@@ -716,9 +721,12 @@ def main():
                                  "note": "factorizations incl. Sigma^-1 and the posterior; failed ones end early"},
             # achieved / frac = MFMA flops the kernel EXECUTES (block-triangular G) over the live event
             # time: never above 1.  The dense-A figure SURVEY 8(d) prices (2 M N^2) is the side key.
-            "roofline": {"bound": "mfma", "kernel": "quadform_kernel (K4: |G K*|^2)", "achieved": executed,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("fused_score_kernel (K2+K3+K4 in one launch: K* in LDS, |G K*|^2, score; flops = the "
+                                    "contraction's, time = the whole launch)") if fused_path else "quadform_kernel (K4: |G K*|^2)",
+                         "achieved": executed,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": executed / PEAK_FP64_MFMA_TFLOPS,
-                         "traffic": None, "avg_launch_ms": qf_avg_ms, "launches": qf_n,
+                         "traffic": None, "avg_launch_ms": qf_avg_ms, "launches": qf_launches,
                          "executed_flops_per_launch": exec_flops,
                          "dense_equivalent_flops_per_launch": algo_flops, "dense_equivalent_tflops": dense_equiv},
             "kernels": {

@@ -66,7 +66,8 @@ PPBO_API int ppbo_last_error(ppbo_ctx* ctx, char* buf, size_t n);
  * src/gp_model.py:110-132).  When enabled, the named hot kernels are bracketed
  * by hipEvents on the caller's stream; ppbo_profile_read synchronises those events and
  * returns the accumulated duration and launch count since the last reset.
- * names: "gram", "kstar", "quadform", "score", "rff_project", "rff_score", "potrf". */
+ * names: "gram", "kstar", "quadform", "score", "rff_project", "rff_score", "potrf", "line_kstar", "line_y",
+ * "line_cov", "line_mc", "fused_score" (the one-launch scoring kernel of models with up to 1024 rows). */
 PPBO_API int ppbo_profile_enable(ppbo_ctx* ctx, int on);
 PPBO_API int ppbo_profile_reset(ppbo_ctx* ctx);
 PPBO_API int ppbo_profile_read(ppbo_ctx* ctx, const char* name, double* h_total_ms, int* h_count);

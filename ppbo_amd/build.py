@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppbo_hip.so")
 STAMP = os.path.join(HERE, ".libppbo_hip.stamp")
-SOURCES = ["capi.hip", "gram.hip", "gemm.hip", "linalg.hip", "fit.hip", "predict.hip", "meangrad.hip", "rff.hip", "lu.hip", "dist.hip"]
+SOURCES = ["capi.hip", "gram.hip", "gemm.hip", "linalg.hip", "fit.hip", "predict.hip", "fused.hip", "meangrad.hip", "rff.hip", "lu.hip", "dist.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fvisibility=hidden"]   # the dynamic symbol table is include/ppbo_hip.h (PPBO_API), nothing else
 

@@ -142,6 +142,12 @@ int ppbo_ctx_create(int device, ppbo_ctx** out) {
   ppbo_ctx* c = new (std::nothrow) ppbo_ctx();
   if (!c) return -2;
   c->device = device;
+  c->fused_score = env_int("PPBO_FUSED", 1);
+  c->fused_dbg = env_int("PPBO_FUSED_DBG", 0);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  }
   c->qf_variant = env_int("PPBO_QF_VARIANT", 2);
   if (c->qf_variant < 0 || c->qf_variant > 5) c->qf_variant = 0;
   c->qf_order = env_int("PPBO_QF_ORDER", 514);
@@ -184,7 +190,7 @@ int ppbo_ctx_destroy(ppbo_ctx* ctx) {
 
 static int pf_slot(const char* name) {
   static const char* names[] = {"gram", "kstar", "quadform", "score", "rff_project", "rff_score", "potrf",
-                                "line_kstar", "line_y", "line_cov", "line_mc"};
+                                "line_kstar", "line_y", "line_cov", "line_mc", "fused_score"};
   for (int i = 0; i < ppbo_ctx::PF_COUNT; ++i)
     if (std::strcmp(name, names[i]) == 0) return i;
   return -1;

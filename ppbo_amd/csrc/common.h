@@ -37,7 +37,7 @@ struct ppbo_ctx {
   unsigned upload_next = 0;
   // optional per-kernel event timing
   bool profiling = false;
-  enum { PF_GRAM = 0, PF_KSTAR, PF_QUADFORM, PF_SCORE, PF_RFF_PROJECT, PF_RFF_SCORE, PF_POTRF, PF_LINE_KSTAR, PF_LINE_Y, PF_LINE_COV, PF_LINE_MC, PF_COUNT };
+  enum { PF_GRAM = 0, PF_KSTAR, PF_QUADFORM, PF_SCORE, PF_RFF_PROJECT, PF_RFF_SCORE, PF_POTRF, PF_LINE_KSTAR, PF_LINE_Y, PF_LINE_COV, PF_LINE_MC, PF_FUSED, PF_COUNT };
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pf_events[PF_COUNT];
   size_t pf_used[PF_COUNT] = {};
   // kernels whose dynamic-LDS limit has been raised on THIS ctx's device (hipFuncSetAttribute is per device)
@@ -45,6 +45,11 @@ struct ppbo_ctx {
   std::vector<int> lds_raised_bytes;
   // tuning knobs, read from the environment once per ctx (ppbo_ctx_create); defaults = measured best
   int qf_variant = 2, qf_order = 514, potrf_gen = 3, rff_nt = 0, gram_variant = -1, rff_score_mfma = 1;
+  // PPBO_FUSED: 1 (default) = models of up to 1024 rows are scored by the one-launch kernel of fused.hip, 0 = always the
+  // three-launch form (kstar -> quadform -> score)
+  int fused_score = 1;
+  int n_cu = 0;           // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+  int fused_dbg = 0;      // PPBO_FUSED_DBG: measurement switches of fused.hip (results are wrong when set)
   // ppbo_gp_fit runs the triangular inverse and Sigma^-1 on a second stream beside the first evaluations of the f_MAP
   // search, which needs only L until the |grad_f| rule is armed (fit.hip)
   int fit_overlap = 1;    // PPBO_FIT_OVERLAP
@@ -96,6 +101,13 @@ int ppbo_host_record(ppbo_ctx* ctx, PpboHostRecord* out);
 // spin until the kernel enqueued on `s` has raised the flag to the record's epoch; falls back to a stream
 // synchronisation (and reports an error if the flag still is not there: the kernel did not run to completion)
 int ppbo_host_record_wait(ppbo_ctx* ctx, const PpboHostRecord& r, hipStream_t s);
+// fused.hip: the one-launch scoring path (K*, contraction, score in one kernel) for models of up to 1024 rows
+struct ppbo_model;
+bool ppbo_fused_eligible(const ppbo_ctx* ctx, const ppbo_model* m);
+const double* ppbo_fused_transposed_G(ppbo_ctx* ctx, const ppbo_model* m, int* ldgt_out, hipStream_t s);
+int ppbo_fused_score(ppbo_ctx* ctx, const ppbo_model* m, const double* Gt, int ldgt, const double* d_Xc, long long M,
+                     int score_kind, double mustar, long long idx_base, double* d_mu, double* d_var, double* d_score,
+                     void* blk_best, hipStream_t s);
 // predict.hip, for dist.hip: one shard's scoring passes with the record published to host-mapped memory
 int ppbo_predict_record_publish(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M, int score_kind,
                                 double mustar, int64_t index_offset, double* d_record, unsigned long long* d_flag,

@@ -796,6 +796,34 @@ static int predict_passes(ppbo_ctx* ctx, const ppbo_model* model, const double* 
                "variance / EI scores need model->d_G");
   PPBO_REQUIRE(ctx, !want_var || (model->d_lam_diag && model->d_lam_off), "model Lambda");
   const int N = model->N, mblk = model->m + 1, n_q = N / mblk;
+  if (want_var && ppbo_fused_eligible(ctx, model)) {
+    // Models of up to 1024 rows: ONE launch forms K* in LDS, contracts it with G on the matrix cores and scores
+    // (fused.hip) -- no K* in HBM, no slab pass, no candidate chunks -- then the one-workgroup argmax.  The choice
+    // depends on the model only: a shard of a sharded search scores a candidate exactly as the unsharded search does.
+    int ldgt = N;
+    const double* Gt = ppbo_fused_transposed_G(ctx, model, &ldgt, s);
+    if (!Gt) return (int)hipErrorOutOfMemory;
+    PPBO_LAUNCH_CHECK(ctx);
+    const long long nblk = (M + 31) / 32;
+    PPBO_REQUIRE(ctx, nblk < ((long long)1 << 31), "candidate count");
+    Best* bests = (Best*)ppbo_workspace(ctx, ppbo_ctx::WS_SMALL, (size_t)(nblk + 1) * sizeof(Best));
+    if (!bests) return (int)hipErrorOutOfMemory;
+    Best* chunk_best = bests + nblk;
+    {
+      PpboProfScope pf(ctx, ppbo_ctx::PF_FUSED, s);
+      if (int rc = ppbo_fused_score(ctx, model, Gt, ldgt, d_Xc, (long long)M, score_kind, mustar, 0, d_mu, d_var, d_score,
+                                    want_best ? bests : nullptr, s))
+        return rc;
+    }
+    if (want_best) {
+      PpboProfScope pfs(ctx, ppbo_ctx::PF_SCORE, s);
+      argmax_final_kernel<<<1, 256, 0, s>>>(bests, (int)nblk, chunk_best, d_record, (long long)record_offset, publish, epoch);
+      PPBO_LAUNCH_CHECK(ctx);
+    }
+    *chunk_best_out = chunk_best;
+    *n_chunks_out = 1;
+    return 0;
+  }
   const int64_t chunk_cap = 65536;
   const int64_t n_chunks = (M + chunk_cap - 1) / chunk_cap;
   const int qf_bm = (quadform_variant(ctx) == 5) ? 256 : 128;
