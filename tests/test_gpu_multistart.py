@@ -84,8 +84,13 @@ def test_multimodal_regime_restarts_are_as_good_as_the_references(eng, name):
         print(f"{name} start {k}: T {st['T']:.8f} (reference {float(z['T'][k]):.8f})")
     print(f"{name}: the reference's 8 runs end in {n_ref_maxima} different maxima; {agree} of 8 default-path runs end where "
           f"the reference's run from the same start does; best of 8: {max(ours):.8f} vs reference {z['T'].max():.8f}")
-    # the reference's guard in this regime is best-of-restarts (gp_model.py:385-387): ours must not be worse
-    assert max(ours) >= float(z["T"].max()) - 1e-6 * max(1.0, abs(float(z["T"].max())))
+    # the reference's guard in this regime is best-of-restarts (gp_model.py:385-387): ours must not be worse -- than the
+    # best T ANY run of the reference has reached on this model (T_best_known: this file's runs and the earlier,
+    # multi-threaded-BLAS ones whose starts differed by 5e-10 and fell into other basins; tools/make_golden_r4.py now pins
+    # one BLAS thread and reproduces the file bit for bit)
+    bar = float(z["T_best_known"])
+    assert bar >= float(z["T"].max())
+    assert max(ours) >= bar - 1e-6 * max(1.0, abs(bar)), (max(ours), bar)
     # and every reference maximum is a fixed point of our optimiser: started AT the reference's result it stays there
     for k in range(K):
         f, st = eng.fit_fmap(Sinv, z["fMAP"][k], m, sig, gtol=1e-4, L=L)
