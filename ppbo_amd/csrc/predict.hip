@@ -63,6 +63,14 @@ __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
   __shared__ __attribute__((aligned(16))) double xs[KS_RJ * DP];
   __shared__ double s_alpha[KS_RJ], s_ld[KS_RJ], s_lo[KS_RJ], s_nx[KS_RJ];
   const int c0 = (blockIdx.x * KS_THREADS + threadIdx.x) * KS_CPT;
+  // The camphor kernel in FEATURE form (fp64 path; DP = 12): sin^2(pi (a - b)) = (1 - cos 2pi a cos 2pi b - sin 2pi a sin 2pi b) / 2
+  // turns kernels.py:36-53's exponent  c0 sum_k sin^2(pi |a_k - b_k|) + c1 (a_2 - b_2)^2  into
+  //   5 c0 / 2 + sum_{f < 10} phi_f(a) psi_f(b) + c1 (a_2 - b_2)^2,  phi = (cos 2pi a_k, sin 2pi a_k)_k,  psi = -(c0 / 2) phi(b):
+  // ten FMAs per pair instead of five sinpi evaluations (~20 instructions each: K* was 1.88 ms of C5's 16.6 ms step, six
+  // times the SE kernel's cost per pair).  The features of a design row are formed once when it is staged (per 512
+  // candidates), those of a candidate once per thread.  Terms of size c0 cancel to the true exponent with an absolute
+  // error of ~1e-15 (the kernel value moves by <= 1e-14 relative; Sigma / K* parity is asserted at 1e-12).
+  constexpr bool CAMF = (KID == PPBO_KERNEL_CAMPHOR) && !F32 && DP == 12;   // (the only fp64 camphor bucket launched)
   // SE / RQ use the reference's own expansion r^2 = (|x|^2 + |c|^2) - 2 x.c (kernels.py:7-10) with the
   // candidate pre-scaled by -2: one FMA per dimension and pair instead of a subtract and an FMA.  Its
   // rounding is the rounding every entry of Sigma already carries (posterior mean / variance move by
@@ -75,6 +83,21 @@ __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
 #pragma unroll
   for (int q = 0; q < KS_CPT; ++q) {
     nc[q] = 0.0; mu[q] = 0.0; tl[q] = 0.0; ko[q] = 0.0;
+    if (CAMF) {
+      // psi: -(c0 / 2) (cos, sin)(2 pi c_k) for the periodic coordinates k = 0, 1, 3, 4, 5; then c_2 itself
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int d = k < 2 ? k : k + 1;
+        const double v = (c0 + q < M) ? Xc[(size_t)(c0 + q) * D + d] : 0.0;
+        double sn, cs;
+        sincospi(2.0 * v, &sn, &cs);
+        xc[q][k] = -0.5 * p.c0 * cs;
+        xc[q][5 + k] = -0.5 * p.c0 * sn;
+      }
+      xc[q][10] = (c0 + q < M) ? Xc[(size_t)(c0 + q) * D + 2] : 0.0;
+      xc[q][11] = 0.0;
+      continue;
+    }
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
       double v = (d < D && c0 + q < M) ? Xc[(size_t)(c0 + q) * D + d] : 0.0;
@@ -91,6 +114,22 @@ __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
   int rb = 0;  // row index inside the current star block (splits start on a block edge)
   for (int row0 = j_beg; row0 < j_end; row0 += KS_RJ) {
     __syncthreads();
+    if (CAMF) {                            // phi of the staged rows: (cos, sin)(2 pi x_k) for k = 0, 1, 3, 4, 5; then x_2
+      for (int e = threadIdx.x; e < KS_RJ * 6; e += KS_THREADS) {
+        const int r = e / 6, k = e - r * 6;
+        const int j = row0 + r;
+        if (k < 5) {
+          const double v = (j < j_end) ? X[(size_t)j * D + (k < 2 ? k : k + 1)] : 0.0;
+          double sn, cs;
+          sincospi(2.0 * v, &sn, &cs);
+          xs[r * DP + k] = cs;
+          xs[r * DP + 5 + k] = sn;
+        } else {
+          xs[r * DP + 10] = (j < j_end) ? X[(size_t)j * D + 2] : 0.0;
+          xs[r * DP + 11] = 0.0;
+        }
+      }
+    } else
     for (int e = threadIdx.x; e < KS_RJ * DP; e += KS_THREADS) {
       const int r = e / DP, d = e - r * DP;
       const int j = row0 + r;
@@ -139,6 +178,19 @@ __global__ __launch_bounds__(KS_THREADS) void kstar_kernel(
         const double nx = s_nx[r];
 #pragma unroll
         for (int q = 0; q < KS_CPT; ++q) sv[q] = fmax(sv[q] + (nx + nc[q]), 0.0);
+      } else if (CAMF) {
+#pragma unroll
+        for (int d = 0; d < 10; ++d) {
+          const double x = xr[d];
+#pragma unroll
+          for (int q = 0; q < KS_CPT; ++q) sv[q] = fma(x, xc[q][d], sv[q]);
+        }
+        const double x2 = xr[10], base = 2.5 * p.c0;
+#pragma unroll
+        for (int q = 0; q < KS_CPT; ++q) {
+          const double dd = x2 - xc[q][10];
+          sv[q] = fma(p.c1 * dd, dd, sv[q] + base);
+        }
       } else {
 #pragma unroll
         for (int d = 0; d < DP; ++d) {
@@ -363,6 +415,33 @@ __global__ __launch_bounds__(256) void line_prior_kernel(const double* __restric
                                                          KernParams p, double shrink, double* __restrict__ cov) {
   const double* xg = grid + (size_t)blockIdx.x * G * D;
   double* c = cov + (size_t)blockIdx.x * G * G;
+  if (KID == PPBO_KERNEL_CAMPHOR) {
+    // feature form of the camphor exponent (see kstar_kernel): (cos, sin)(2 pi x_k) of the line's points once, then ten
+    // FMAs per pair; the same chain of the same products for (g, h) and (h, g)
+    __shared__ double ph[128 * 11];        // G <= 128 (line_acq_impl)
+    for (int e = threadIdx.x; e < G * 6; e += blockDim.x) {
+      const int g = e / 6, k = e - g * 6;
+      if (k < 5) {
+        double sn, cs;
+        sincospi(2.0 * xg[g * D + (k < 2 ? k : k + 1)], &sn, &cs);
+        ph[g * 11 + k] = cs;
+        ph[g * 11 + 5 + k] = sn;
+      } else {
+        ph[g * 11 + 10] = xg[g * D + 2];
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < G * G; e += blockDim.x) {
+      const int g = e / G, h = e - g * G;
+      double dot = 0.0;
+#pragma unroll
+      for (int f = 0; f < 10; ++f) dot = fma(ph[g * 11 + f], ph[h * 11 + f], dot);
+      const double dd = ph[g * 11 + 10] - ph[h * 11 + 10];
+      const double s = fma(p.c1 * dd, dd, 0.5 * p.c0 * (5.0 - dot));
+      c[e] = (g == h) ? ((1.0 - shrink) * p.sf2 + shrink * p.sf2) : (1.0 - shrink) * kern_finish<KID>(s, p);
+    }
+    return;
+  }
   for (int e = threadIdx.x; e < G * G; e += blockDim.x) {
     const int g = e / G, h = e - g * G;
     double s = 0.0;
@@ -729,7 +808,7 @@ int launch_kstar(const ppbo_model* m, const KernParams& p, const double* d_Xc, i
   kstar_kernel<KID, DP><<<grid, KS_THREADS, 0, s>>>(m->d_X, m->N, m->D, p, m->d_alpha, ld, lo, mblk, d_Xc, M, \
                                                     Kt, ldk, mu_part, with_lam ? t_part : nullptr,            \
                                                     q_per_split, n_q)
-  if (KID == PPBO_KERNEL_CAMPHOR) KS_LAUNCH(6);
+  if (KID == PPBO_KERNEL_CAMPHOR) KS_LAUNCH(12);      // the feature form: 12 staged values per row
   else if (m->D <= 4) KS_LAUNCH(4);
   else if (m->D <= 6) KS_LAUNCH(6);
   else if (m->D <= 8) KS_LAUNCH(8);
