@@ -238,6 +238,67 @@ WORKLOADS = {
 }
 
 
+def other_config_row(torch, eng, cfg, steps=20):
+    """One BASELINE configuration other than the headline one, measured inside the default run so that the DRIVER's clock
+    covers it: the cold fit (median of three after a warm-up) and `steps` scoring steps of the config's own
+    candidate count on this GPU, with the dominant kernel's executed-flops fraction of the fp64 MFMA peak."""
+    from ppbo_amd.dist import ShardedSearch
+    from ppbo_amd.engine import SCORE_POINTWISE_EI
+    g = synth_model_inputs(cfg)
+    X, th, m, kern = g["X"], g["theta"], int(g["m"]), str(g["kernel"])
+    N, D = X.shape
+    M = WORKLOADS[cfg][1]
+    Xd = eng.dev(X)
+    if bool(g.get("f_init_is_warm_start", False)):
+        Ls = eng.potrf_(eng.gram(Xd, th, kern).clone())
+        f_init = eng.dgemv(Ls, np.random.default_rng(2).standard_normal(N), lower=True)
+        del Ls
+    else:
+        f_init = eng.dev(g["f_init"])
+    fit = lambda: eng.gp_fit(Xd, th, kern, m, f_init, gtol=1e-4, start_is_whitened=False)
+    r = fit()
+    torch.cuda.synchronize()
+    runs = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r = fit()
+        torch.cuda.synchronize()
+        runs.append((time.perf_counter() - t0) * 1e3)
+    post = r["post"]
+    Xc = eng.dev(np.random.default_rng(1).random((M, D)))
+    mustar = float(np.max(g["mu"]))
+    search = ShardedSearch(eng, post, Xc, 0, SCORE_POINTWISE_EI, mustar)
+    for _ in range(3):
+        search.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        search.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    eng.profile(True)
+    for _ in range(5):
+        search.step()
+    torch.cuda.synchronize()
+    qf, qn = eng.profile_read("quadform")
+    fu, fn_ = eng.profile_read("fused_score")
+    ks, kn = eng.profile_read("kstar")
+    eng.profile(False)
+    fused = fn_ > 0 and qn == 0
+    mblk = m + 1
+    launches_per_step = 1 if fused else max(1, -(-M // 65536))
+    M_launch = float(M) / launches_per_step
+    exec_flops = sum(2.0 * 32 * M_launch * min(N, -(-((b + 1) * 32) // mblk) * mblk) for b in range(-(-N // 32)))
+    k_ms = (fu / max(fn_, 1)) if fused else qf / max(qn, 1)
+    del search, Xc, post, r
+    return {"workload": WORKLOADS[cfg][0], "N": N, "D": D, "M": M, "ms_per_step": dt * 1e3, "evals_per_s": M / dt,
+            "gp_fit_ms_from_f_init": float(np.median(runs)),
+            "dominant_kernel": "fused_score_kernel (one launch: K* in LDS + contraction + score)" if fused else "quadform_kernel",
+            "dominant_kernel_ms": k_ms, "launches_per_step": launches_per_step,
+            "frac_of_fp64_mfma_peak": exec_flops / (k_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+            "kstar_kernel_ms": None if fused else ks / max(kn, 1)}
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` outside torchrun: start N rank processes (one per GPU, RCCL) as a CHILD job and
     relay its output.  Nothing in this parent has touched HIP (torch is not even imported), so no process that
@@ -372,15 +433,32 @@ def main():
         fmap, st = eng.fit_fmap(Sinv, f_init, m, th[0], gtol=1e-4, L=None)
         post = eng.posterior(Xd, th, kern, Sinv, fmap, m)
         return post, st
-    post, st = fit_once()            # warm (allocates workspaces)
+    def fit_from_f_init():
+        """The protocol's fit ('timed end to end with the stored f_init'): the SAME library call
+        handed f_init itself -- nothing precomputed outside the timed call; the library whitens it with the factor's
+        inverse (z0 = L^-1 f_init), so the search's stream waits for the triangular inverse before its first evaluation
+        instead of running beside it."""
+        r = eng.gp_fit(Xd, th, kern, m, f_init, gtol=1e-4, start_is_whitened=False)
+        return r["post"], r["stats"]
+    post, st = fit_once()            # warm-up (allocates workspaces)
     torch.cuda.synchronize()
+    n_fit = 5 if N <= 2048 else 3    # BASELINE.md section 3: one warm-up, then the MEDIAN of five runs (three beyond N = 2048)
     fit_runs = []
-    for _ in range(3 if N <= 2048 else 1):   # the same deterministic cold fit (three times up to N = 2048): best run reported, all listed
+    for _ in range(n_fit):           # the same deterministic cold fit every time
         t0 = time.perf_counter()
         post, st = fit_once()
         torch.cuda.synchronize()
         fit_runs.append((time.perf_counter() - t0) * 1e3)
-    gp_fit_ms = min(fit_runs)
+    gp_fit_ms = float(np.median(fit_runs))
+    fit_from_f_init()                # warm-up of the other start kind
+    torch.cuda.synchronize()
+    fit_runs_f = []
+    for _ in range(n_fit):
+        t0 = time.perf_counter()
+        _, st_f = fit_from_f_init()
+        torch.cuda.synchronize()
+        fit_runs_f.append((time.perf_counter() - t0) * 1e3)
+    gp_fit_ms_from_f_init = float(np.median(fit_runs_f))
     eng.profile(True)                # one more fit with the library's event brackets: where the fit time goes
     fit_once()
     torch.cuda.synchronize()
@@ -663,6 +741,14 @@ def main():
             secondary["c1_loop"] = c1_loop(torch)
         except Exception as exc:          # noqa: BLE001
             secondary["c1_loop"] = {"error": repr(exc)}
+        # the other BASELINE configurations on this GPU (the headline line is args.config): ~10 s in all
+        for oc in ("c2", "c4", "c5"):
+            if oc == args.config:
+                continue
+            try:
+                secondary[f"config_{oc}"] = other_config_row(torch, eng, oc)
+            except Exception as exc:      # noqa: BLE001  -- a secondary row must never cost the headline line
+                secondary[f"config_{oc}"] = {"error": repr(exc)}
         for pq_cfg in ("c2", "c3"):
             try:
                 secondary[f"per_query_ms_{pq_cfg}"] = per_query_breakdown(torch, pq_cfg)
@@ -708,7 +794,12 @@ def main():
                                        else "the library's own RCCL communicator (ppbo_search_sharded)"))},
             "ms_per_step_with_event_brackets": elapsed_bracketed / args.steps * 1e3,
             "collective_roundtrip_us": coll_us,
-            "gp_fit_ms": gp_fit_ms, "gp_fit_ms_runs": fit_runs, "gp_fit_start": fit_start, "gp_fit_iterations": st["iterations"],
+            "gp_fit_ms": gp_fit_ms, "gp_fit_ms_runs": fit_runs, "gp_fit_ms_min": min(fit_runs),
+            "gp_fit_ms_from_f_init": gp_fit_ms_from_f_init, "gp_fit_ms_from_f_init_runs": fit_runs_f,
+            "gp_fit_ms_protocol": "median of %d timed runs after one warm-up; gp_fit_ms: start handed over as z0 = L^-1 f_init "
+                                  "(what the drop-in does: it draws z0 itself); gp_fit_ms_from_f_init: the stored f_init itself, "
+                                  "nothing precomputed outside the timed call (%d L-BFGS evaluations)" % (n_fit, st_f["lbfgs_evals"]),
+            "gp_fit_start": fit_start, "gp_fit_iterations": st["iterations"],
             "gp_fit_cholesky": st["n_cholesky"],
             "replicated_fit_bitwise_equal": replicated_equal,
             "gp_fit_method": "ppbo_gp_fit: one call = Gram, Cholesky, [triangular inverse, Sigma^-1 on a second stream beside the first evaluations], whitened L-BFGS (z = L^-1 f; "
@@ -744,21 +835,43 @@ def main():
             "best": {"value": best[0], "index": best[1]},
             ("weak_scaling_leg" if scaling == "strong" else "strong_scaling_leg"): other_leg,
         }
-        # `traffic` needs rocprofv3 --pmc passes and cannot be measured from inside this process: it stays null.
-        # The last committed PMC capture is quoted beside it ONLY while the kernel sources are the ones it was
-        # taken with (tools/pmc_quadform.sh records the csrc digest).
+        # `traffic` = HBM-side (fabric) bytes per launch of the dominant kernel from the PMC counters.  rocprofv3 --pmc passes
+        # cannot run inside this process: the number comes from the last committed capture (profiles/r0*_pmc_hot_kernels.json:
+        # FETCH_SIZE x 2 -- the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md -- + WRITE_SIZE), and ONLY while
+        # it belongs to this launch shape; `traffic_source.current` says whether the kernel sources are still the ones it
+        # was taken with (tools/pmc_quadform.sh / tools/dev/r6_fused_pmc.sh record the csrc digest).  `algorithmic_bytes` is
+        # what the launch must move: three-launch form = K* once + G's block triangle + the slab written; one-launch form
+        # = candidates + G's block triangle once per 32 candidates' workgroup (L2 traffic, not HBM: G is L2-resident) --
+        # there the HBM-side figure is the candidates, X and G once.
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_hot_kernels.json")))
         pmc = pmcs[-1] if pmcs else ""
+        tri = sum(8.0 * wrows * min(N, -(-((b + 1) * wrows) // mblk) * mblk) for b in range(-(-N // wrows)))   # G's block triangle
+        if fused_path:
+            line["roofline"]["algorithmic_bytes"] = 8.0 * (M_launch * D + N * D + 3 * N) + tri + 16.0 * (M_launch / 32)
+        else:
+            line["roofline"]["algorithmic_bytes"] = 8.0 * N * M_launch + tri + 8.0 * (-(-N // 128)) * M_launch
         if pmc and os.path.exists(pmc):
             try:
                 from ppbo_amd.build import _digest
                 doc = json.load(open(pmc))
-                d = doc["quadform"]["derived"]
-                line["roofline"]["traffic_from_profile"] = {
-                    "bytes_per_launch": d["fabric_read_bytes(FETCH_SIZE KB x1024 x2 gfx950 correction)"] + d["write_bytes"],
-                    "source": f"profiles/{os.path.basename(pmc)} (FETCH_SIZE x2 + WRITE_SIZE, C3 launch)",
+                key = "fused_score" if fused_path else "quadform"
+                ent = doc.get(key) or {}
+                d = ent.get("derived") or {}
+                shape_ok = ent.get("shape", {"N": 2048, "M": 65536}) == {"N": N, "M": int(M_launch)}
+                if d and shape_ok:
+                    line["roofline"]["traffic"] = d["fabric_read_bytes(FETCH_SIZE KB x1024 x2 gfx950 correction)"] + d["write_bytes"]
+                    line["roofline"]["traffic_over_algorithmic"] = line["roofline"]["traffic"] / line["roofline"]["algorithmic_bytes"]
+                line["roofline"]["traffic_source"] = {
+                    "file": f"profiles/{os.path.basename(pmc)}", "entry": key, "shape_matches_this_launch": bool(d and shape_ok),
+                    "counters": "FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes, per launch",
                     "csrc_digest": doc.get("csrc_digest"), "current": doc.get("csrc_digest") == _digest()}
+                # (the key earlier rounds printed; kept so that old and new lines compare)
+                if d:
+                    line["roofline"]["traffic_from_profile"] = {
+                        "bytes_per_launch": d["fabric_read_bytes(FETCH_SIZE KB x1024 x2 gfx950 correction)"] + d["write_bytes"],
+                        "source": f"profiles/{os.path.basename(pmc)} ({key})",
+                        "csrc_digest": doc.get("csrc_digest"), "current": doc.get("csrc_digest") == _digest()}
             except Exception:
                 pass
         # model on the REFERENCE's f_MAP (fixture): parity of the timed path on the fixture's candidates, and
