@@ -99,7 +99,11 @@ class ShardedSearch:
     def step(self):
         """-> job-wide (best score, global row index), identical on every rank."""
         eng = self.eng
-        if self.collective == "capi" and not self.host:
+        # one rank and no process group: the library call that scores and publishes the record through the ctx's
+        # host-mapped block (the host polls a flag) -- ppbo_predict_record + record.tolist() paid a device-to-host copy and
+        # a stream synchronisation for 16 bytes (~10 us of a 120 us step at C2)
+        single = self.world == 1 and not self.host and not (dist.is_available() and dist.is_initialized())
+        if (self.collective == "capi" or single) and not self.host:
             rc = eng.lib.ppbo_search_sharded(eng.ctx, self._md_ref, self._xc_ptr, self._M, int(self.score), self.mustar,
                                              self.offset, self._bv_ref, self._bi_ref, eng._stream())
             eng._check(rc, "ppbo_search_sharded")
