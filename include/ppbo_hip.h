@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PPBO_ABI_VERSION 5
+#define PPBO_ABI_VERSION 6
 #define PPBO_ERR_NOT_PD 1001
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY dynamic symbols
@@ -280,7 +280,17 @@ typedef struct ppbo_model {
   int kstar_fp32;           /* 0: everything fp64 (the product path).  1: K* entries evaluated in fp32 from direct
                              * differences, all accumulation fp64 -- BASELINE config 5's "fp32 tolerance" variant;
                              * its error against the fp64 path is REPORTED (bench.py), it does not meet 1e-5 */
+  const double* d_Gt;       /* optional (ABI 6): the TRANSPOSE of d_G as ppbo_transposed_G writes it.  Models of up to ~500
+                             * rows are scored by one launch (csrc/fused.hip) whose matrix-core loop reads G transposed;
+                             * NULL: the library forms the transpose in a workspace on every call (2-4 us) */
 } ppbo_model;
+
+/* The transpose of G = R Lambda in the layout the one-launch scoring kernel reads: d_Gt[rows][ld] with
+ * rows = (N rounded up to 16) + 16, ld = (N rounded up to 32) + 32 (ppbo_transposed_G_shape), d_Gt[k][i] = d_G[i][k] for
+ * i, k < N and zero elsewhere.  Form it once per fit and hand it over as ppbo_model.d_Gt.  No reference counterpart (G
+ * itself replaces the dense A = Sigma^-1 - Sigma^-1 P Sigma^-1 of src/gp_model.py:449). */
+PPBO_API int ppbo_transposed_G_shape(int N, int* rows, int* ld);
+PPBO_API int ppbo_transposed_G(ppbo_ctx* ctx, const double* d_G, int N, double* d_Gt, void* stream);
 PPBO_API int ppbo_predict(ppbo_ctx* ctx, const ppbo_model* model, const double* d_Xc, int64_t M,
                  int score_kind, double mustar, double* d_mu, double* d_var, double* d_score,
                  double* h_best_val, int64_t* h_best_idx, void* stream);

@@ -35,7 +35,8 @@ class FitStats(C.Structure):
 class Model(C.Structure):
     _fields_ = [("kernel_id", C.c_int), ("N", C.c_int), ("D", C.c_int), ("m", C.c_int),
                 ("theta", C.c_double * 3), ("d_X", C.c_void_p), ("d_alpha", C.c_void_p),
-                ("d_lam_diag", C.c_void_p), ("d_lam_off", C.c_void_p), ("d_G", C.c_void_p), ("kstar_fp32", C.c_int)]
+                ("d_lam_diag", C.c_void_p), ("d_lam_off", C.c_void_p), ("d_G", C.c_void_p), ("kstar_fp32", C.c_int),
+                ("d_Gt", C.c_void_p)]
 
 
 _vp, _i, _d, _i64 = C.c_void_p, C.c_int, C.c_double, C.c_int64
@@ -71,6 +72,8 @@ SIGNATURES = {
     "ppbo_predict": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _vp, _vp, _vp, C.POINTER(_d), C.POINTER(_i64), _vp],
     "ppbo_predict_record": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _i64, _vp, _vp],
     "ppbo_predict_cov": [_vp, C.POINTER(Model), _vp, _i, _d, _vp, _vp, _vp],
+    "ppbo_transposed_G_shape": [_i, C.POINTER(_i), C.POINTER(_i)],
+    "ppbo_transposed_G": [_vp, _vp, _i, _vp, _vp],
     "ppbo_mean_grad": [_vp, C.POINTER(Model), _vp, C.c_int64, _vp, _vp, _vp],
     "ppbo_mean_search": [_vp, C.POINTER(Model), _vp, _i64, _i, _d, _i, _d, _vp, _vp, C.POINTER(_i), _vp],
     "ppbo_mean_ascent": [_vp, C.POINTER(Model), _vp, _i, _i, _d, _vp, _vp, _vp, _vp],
@@ -98,7 +101,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5     # must equal PPBO_ABI_VERSION of include/ppbo_hip.h
+ABI_VERSION = 6     # must equal PPBO_ABI_VERSION of include/ppbo_hip.h
 
 
 def _check_stamp():

@@ -563,12 +563,34 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const double* __rest
 // columns from an even row index below N), zeros outside [N][N]; ~2 us at N = 512, ~4 us at N = 1024.
 const double* ppbo_fused_transposed_G(ppbo_ctx* ctx, const ppbo_model* m, int* ldgt_out, hipStream_t s) {
   const int N = m->N, rows_t = ((N + 15) & ~15) + 16, ldgt = ((N + 31) & ~31) + 32;
+  *ldgt_out = ldgt;
+  if (m->d_Gt) return m->d_Gt;            // formed once per fit by the caller (ppbo_transposed_G)
   double* Gt = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_GPAD, (size_t)rows_t * ldgt * sizeof(double));
   if (!Gt) return nullptr;
   transpose_pad_kernel<<<dim3(ldgt / 32, (rows_t + 31) / 32), 256, 0, s>>>(m->d_G, N, Gt, rows_t, ldgt);
-  *ldgt_out = ldgt;
   return Gt;
 }
+
+extern "C" {
+
+int ppbo_transposed_G_shape(int N, int* rows, int* ld) {
+  if (N <= 0 || !rows || !ld) return -1;
+  *rows = ((N + 15) & ~15) + 16;
+  *ld = ((N + 31) & ~31) + 32;
+  return 0;
+}
+
+int ppbo_transposed_G(ppbo_ctx* ctx, const double* d_G, int N, double* d_Gt, void* stream) {
+  PPBO_ENTER(ctx);
+  PPBO_REQUIRE(ctx, d_G && d_Gt && N > 0, "G / Gt / N");
+  int rows_t = 0, ldgt = 0;
+  (void)ppbo_transposed_G_shape(N, &rows_t, &ldgt);
+  transpose_pad_kernel<<<dim3(ldgt / 32, (rows_t + 31) / 32), 256, 0, (hipStream_t)stream>>>(d_G, N, d_Gt, rows_t, ldgt);
+  PPBO_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+}  // extern "C"
 
 // does the one-launch form take this model?  (a property of the MODEL, never of the candidate count: a sharded search
 // and the unsharded one must score a candidate with the same arithmetic)

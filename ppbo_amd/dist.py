@@ -184,4 +184,5 @@ def broadcast_posterior(post, src: int = 0, group=None):
     for t in (post.alpha, post.lam_diag, post.lam_off, post.G):
         if t is not None:
             dist.broadcast(t, src=src, group=group)
+    post.Gt = None            # the cached transpose of G (engine._model) belongs to the old contents
     return post

@@ -32,6 +32,7 @@ class Posterior:
     lam_off: torch.Tensor    # [N]
     G: torch.Tensor | None   # [N, N] R Lambda
     P: torch.Tensor | None = None  # posterior covariance (optional)
+    Gt: torch.Tensor | None = None  # transpose of G in the one-launch scoring kernel's layout (formed on first use)
 
 
 def _ptr(t):
@@ -103,7 +104,23 @@ class Engine:
         md.d_lam_off = post.lam_off.data_ptr() if post.lam_off is not None else 0
         md.d_G = post.G.data_ptr() if (with_var and post.G is not None) else 0
         md.kstar_fp32 = int(bool(kstar_fp32))
+        md.d_Gt = 0
+        if md.d_G and N <= 1024 and post.kernel != "camphor_copper_kernel":
+            # models the one-launch scoring kernel takes: its matrix-core loop reads G transposed -- formed ONCE per
+            # posterior here (the library would otherwise do it in a workspace on every call)
+            if post.Gt is None or post.Gt.device != post.G.device:
+                post.Gt = self.transposed_G(post.G)
+            md.d_Gt = post.Gt.data_ptr()
         return md
+
+    def transposed_G(self, G):
+        """G [N, N] -> its transpose in the layout of ppbo_model.d_Gt (ppbo_transposed_G)."""
+        N = G.shape[0]
+        rows, ld = C.c_int(0), C.c_int(0)
+        self._check(self.lib.ppbo_transposed_G_shape(N, C.byref(rows), C.byref(ld)), "ppbo_transposed_G_shape")
+        Gt = self.empty(rows.value, ld.value)
+        self._check(self.lib.ppbo_transposed_G(self.ctx, _ptr(G), N, _ptr(Gt), self._stream()), "ppbo_transposed_G")
+        return Gt
 
     # ---- the path's collective behind the C-ABI (RCCL; no torch.distributed needed) -----------------
     def dist_unique_id(self) -> bytes:

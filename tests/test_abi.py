@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"libppbo_hip.so does not export {s}"
         assert s in _lib.SIGNATURES, f"ctypes binding lacks {s}"
     assert set(_lib.SIGNATURES) == set(header_symbols())
-    assert lib.ppbo_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.ppbo_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_library_exports_nothing_but_the_c_abi():
