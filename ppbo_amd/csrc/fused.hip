@@ -88,6 +88,13 @@ __device__ __forceinline__ void fs_chunk(const AFrag& f, int lb, int lb_next, do
   b0 = lds_vread(lb_next); b1 = lds_vread(lb_next + 16);
   acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.f[3], n0, acc[0], 0, 0, 0);
   acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.f[3], n1, acc[1], 0, 0, 0);
+  // the order above IS the schedule: the two reads of the NEXT k-step, then the two MFMAs of the current one (left alone,
+  // the scheduler moves every read down to just above its MFMA and the LDS latency shows at two wavefronts per SIMD)
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+  }
 }
 
 // acc += G[strip rows][kb, ke) K*[kb, ke)[32 candidates] for a strip of 16 rows; ke - kb a positive multiple of 16.
@@ -180,6 +187,11 @@ __device__ __forceinline__ void fs_chunk2(const AFrag2& f, int lb, int lb_next, 
     acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.fb[s4], b0, acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.fb[s4], b1, acc[1][1], 0, 0, 0);
     b0 = n0; b1 = n1;
+  }
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {         // the schedule: next step's two reads, then this step's four MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
   }
 }
 __device__ __forceinline__ void fs_pair(const double* __restrict__ gta, const double* __restrict__ gtb, int ldgt,
