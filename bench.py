@@ -332,6 +332,9 @@ def main():
                     help="initialise torch.distributed (nccl) and run the collective path even with ONE rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the RFF / line-acquisition side measurements")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the secondary rows config_c2 / _c4 / _c5 (counter passes: every hot kernel of the run then has "
+                         "ONE benchmark-shaped launch size)")
     ap.add_argument("--no-precision-report", action="store_true",
                     help="skip the fp64 / fp32-K* report on the fixture's 512 candidates (with --no-secondary and "
                          "--no-cpu-baseline every kernel row of a rocprofv3 --stats run is then ONE launch shape)")
@@ -743,7 +746,7 @@ def main():
             secondary["c1_loop"] = {"error": repr(exc)}
         # the other BASELINE configurations on this GPU (the headline line is args.config): ~10 s in all
         for oc in ("c2", "c4", "c5"):
-            if oc == args.config:
+            if oc == args.config or args.no_other_configs:
                 continue
             try:
                 secondary[f"config_{oc}"] = other_config_row(torch, eng, oc)

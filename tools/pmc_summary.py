@@ -1,14 +1,17 @@
 """Collapse the rocprofv3 --pmc passes written by tools/pmc_quadform.sh into one JSON: per hot kernel the
 per-launch average of every counter (dispatches of the same kernel averaged; multi-instance counters summed per
 dispatch by rocprofv3 already), plus the derived figures DESIGN.md quotes.
-usage: python tools/pmc_summary.py gpurun_out/pmc > profiles/r03_pmc_hot_kernels.json"""
+usage: python tools/pmc_summary.py gpurun_out/pmc [gpurun_out/pmc_c2 ...] > profiles/r06_pmc_hot_kernels.json
+(round 6: several roots -- the C3 passes of tools/pmc_quadform.sh and the C2 passes of tools/dev/r6_pmc.sh for the one-launch
+scoring kernel; every entry carries the launch shape it was taken at, which bench.py checks before quoting its traffic)"""
 import csv, glob, json, os, sys, collections
 
-root = sys.argv[1]
-HOT = {"quadform": "quadform_kernel", "kstar": "kstar_kernel", "gram_mfma": "gram_mfma_kernel", "score_kernel": "score_kernel",
+roots = sys.argv[1:]
+HOT = {"quadform": "quadform_kernel", "fused_score": "fused_score_kernel", "kstar": "kstar_kernel", "gram_mfma": "gram_mfma_kernel", "score_kernel": "score_kernel",
        "rff_project": "rff_project_kernel", "potrf_step": "potrf_step_kernel"}
 out = {k: {} for k in HOT}
-for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
+paths = [p for root in roots for p in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True)]
+for path in paths:
     per = collections.defaultdict(lambda: collections.defaultdict(float))   # (kernel, counter) -> dispatch -> value
     grid = {}                                                                # (kernel, dispatch) -> grid size
     with open(path) as f:
@@ -33,13 +36,19 @@ for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), 
             vals = vals[1:]                      # drop the warm-up launch
         out[key][ctr] = sum(vals) / len(vals)
         out[key]["launches_averaged"] = len(vals)
-q = out["quadform"]
-if "SQ_INSTS_MFMA" in q:
+SHAPES = {"quadform": {"N": 2048, "M": 65536}, "fused_score": {"N": 512, "M": 16384}}     # bench.py's C3 / C2 launches
+for qkey in ("quadform", "fused_score"):
+    q = out[qkey]
+    if "SQ_INSTS_MFMA" not in q:
+        continue
+    q["shape"] = SHAPES[qkey]
     d = {}
     d["mfma_flops_per_launch"] = q["SQ_INSTS_MFMA"] * 2048.0          # v_mfma_f64_16x16x4: 16*16*4*2 flops
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in q and "SQ_BUSY_CYCLES" in q and "GRBM_GUI_ACTIVE" in q:
-        # busy cycles are summed over the 4 SIMDs of 256 CUs; GRBM_GUI_ACTIVE is averaged over 8 XCDs by the pass
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in q and "GRBM_GUI_ACTIVE" in q:
+        # busy cycles are summed over the 4 SIMDs of 256 CUs; GRBM_GUI_ACTIVE is summed over the 8 XCDs by the pass
         d["mfma_busy_frac"] = q["SQ_VALU_MFMA_BUSY_CYCLES"] / (q["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4) if q["GRBM_GUI_ACTIVE"] else None
+    if "SQ_INSTS_VALU" in q:
+        d["vector_instructions_besides_mfma"] = q["SQ_INSTS_VALU"] - q["SQ_INSTS_MFMA"]
     if "FETCH_SIZE" in q:
         d["fabric_read_bytes(FETCH_SIZE KB x1024 x2 gfx950 correction)"] = q["FETCH_SIZE"] * 1024.0 * 2.0
     if "WRITE_SIZE" in q:
