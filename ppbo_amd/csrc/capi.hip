@@ -148,7 +148,7 @@ int ppbo_ctx_create(int device, ppbo_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   }
-  c->qf_variant = env_int("PPBO_QF_VARIANT", 2);
+  c->qf_variant = env_int("PPBO_QF_VARIANT", 4);
   if (c->qf_variant < 0 || c->qf_variant > 5) c->qf_variant = 0;
   c->qf_order = env_int("PPBO_QF_ORDER", 514);
   c->line_y_chunk = env_int("PPBO_LINE_Y_CHUNK", 0);

@@ -11,11 +11,11 @@
 //   and read as broadcasts (SE / RQ: the reference's expansion with the candidate pre-scaled by -2, one FMA
 //   per dimension; camphor: differences); writes K*[N, Mc] (j-major) once and reduces mu and k*'Lambda k*
 //   in registers.
-// Pass 2 (quadform_kernel, fp64 MFMA): Y = G K* on 128x128 tiles (8 wavefronts of 32x64), K range cut
+// Pass 2 (quadform_kernel, fp64 MFMA): Y = G K* on 128x128 tiles (16 wavefronts of 32x32), K range cut
 //   at the block-triangular edge per wavefront, epilogue = column sums of Y^2 into per-row-tile slabs.
 //   Workgroups are ordered candidate-tile-fastest in chunks of 128 tiles (PPBO_QF_ORDER, default 514):
 //   all resident workgroups stream the same G row panel out of L2 while their K* chunk sits in the
-//   Infinity Cache.  PPBO_QF_VARIANT (default 2) selects the measured tile shapes, see DESIGN.md.
+//   Infinity Cache.  PPBO_QF_VARIANT (default 4: 16 wavefronts of 32x32) selects the measured tile shapes, see DESIGN.md.
 // Pass 3 (score_kernel): slab sums -> var, score, per-block argmax; (argmax_final_kernel) -> 1 value.
 #include "gemm_f64.h"
 #include "linalg.h"
@@ -340,7 +340,11 @@ int launch_quadform(ppbo_ctx* ctx, const double* G, int N, int g_rows, int n_row
   return 0;
 }
 
-// ctx->qf_variant (PPBO_QF_VARIANT); default 2 = measured best on MI355X: 8 waves of 32x64, 4 waves/SIMD
+// ctx->qf_variant (PPBO_QF_VARIANT); default 4 since round 6: 16 wavefronts of 32x32, two workgroups per CU = 8 waves/SIMD.
+// Rounds 1-5 shipped variant 2 (8 wavefronts of 32x64, 4 waves/SIMD: the winner of round 1's sweep, 58.1 against 54.7 TF, taken
+// BEFORE the lean main loop); re-measured interleaved on one box in round 6: variant 4 3.74-3.75 ms against 3.78-3.79 at C3 (0.948
+// against 0.938 of the MFMA peak), 0.979 against 0.996 ms at C4 (0.921 / 0.906), level at C5 -- with no vector instruction left in
+// the loop to pay for, twice the wavefronts hide more of the LDS and barrier latency
 int quadform_variant(const ppbo_ctx* ctx) { return ctx->qf_variant; }
 
 int dispatch_quadform(ppbo_ctx* ctx, const double* G, int N, int g_rows, int n_rows, const double* Kt, int ldk, int Mc,
