@@ -143,6 +143,7 @@ int ppbo_ctx_create(int device, ppbo_ctx** out) {
   if (!c) return -2;
   c->device = device;
   c->fused_score = env_int("PPBO_FUSED", 1);
+  c->gemm_big16 = env_int("PPBO_GEMM_BIG16", 1);
   c->fused_dbg = env_int("PPBO_FUSED_DBG", 0);
   {
     hipDeviceProp_t prop;

@@ -48,6 +48,7 @@ struct ppbo_ctx {
   // PPBO_FUSED: 1 (default) = models of up to 1024 rows are scored by the one-launch kernel of fused.hip, 0 = always the
   // three-launch form (kstar -> quadform -> score)
   int fused_score = 1;
+  int gemm_big16 = 1;     // PPBO_GEMM_BIG16: large GEMMs on 16 wavefronts of 32 x 32 (default since round 6) instead of 8 of 32 x 64
   int n_cu = 0;           // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   int fused_dbg = 0;      // PPBO_FUSED_DBG: measurement switches of fused.hip (results are wrong when set)
   // ppbo_gp_fit runs the triangular inverse and Sigma^-1 on a second stream beside the first evaluations of the f_MAP

@@ -8,6 +8,9 @@ namespace {
 
 using namespace gemm64;
 using GCBig = Cfg<4, 2, 2, 4>;     // 128 x 128 tile, 8 wavefronts of 32 x 64 (4 waves/SIMD): large products
+using GCBig16 = Cfg<4, 4, 2, 2>;  // the same tile as 16 wavefronts of 32 x 32 (8 waves/SIMD): the default for large products since
+                                  // round 6 (Y = G K* of 512 lines at C3: 2.18 against 2.23 ms; same bits: the order of a K sum does
+                                  // not depend on the tile shape); PPBO_GEMM_BIG16=0 selects GCBig
 using GCSmall = Cfg<2, 2, 2, 2>;   // 64 x 64 tile, 4 wavefronts of 32 x 32: short-K panel updates, where the
                                    // grid must put >= 2 wavefronts on every SIMD to reach the 64-cycle MFMA rate
 using GCTiny = Cfg<2, 2, 1, 1>;    // 32 x 32 tile, 4 wavefronts of 16 x 16: products with so few 64 x 64 tiles that a CU
@@ -15,7 +18,7 @@ using GCTiny = Cfg<2, 2, 1, 1>;    // 32 x 32 tile, 4 wavefronts of 16 x 16: pro
                                    // cycles) cannot cover a memory round trip; four small workgroups per CU can
 
 template <class GC, int ALAY, int BLAY>
-__global__ __launch_bounds__(GC::NT, (GC::NT == 512) ? 4 : 2) void dgemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(GC::NT, (GC::NT == 1024) ? 8 : (GC::NT == 512) ? 4 : 2) void dgemm_kernel(GemmArgs g) {
   constexpr bool PRELOAD = (GC::NT == 256);   // the small-tile configuration (latency-bound panel updates)
   constexpr int BM = GC::BM, BN = GC::BN;
   if (g.batch > 1) {
@@ -127,7 +130,8 @@ int ppbo_gemm_launch(ppbo_ctx* ctx, const GemmArgs& g, int transA, int transB, h
   // big tiles only when they still give every CU several workgroups
   const long long big_tiles = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.batch > 1 ? g.batch : 1) /
                               (g.lower_only ? 2 : 1);
-  if (big_tiles >= 1024 && g.K >= 256) return launch_cfg<GCBig>(ctx, g, transA, transB, s);
+  if (big_tiles >= 1024 && g.K >= 256)
+    return ctx->gemm_big16 ? launch_cfg<GCBig16>(ctx, g, transA, transB, s) : launch_cfg<GCBig>(ctx, g, transA, transB, s);
   const long long small_tiles = (long long)((g.M + 63) / 64) * ((g.N + 63) / 64) * (g.batch > 1 ? g.batch : 1) /
                                 (g.lower_only ? 2 : 1);
   if (small_tiles <= 384 && g.K >= 128) return launch_cfg<GCTiny>(ctx, g, transA, transB, s);
