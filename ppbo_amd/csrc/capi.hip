@@ -151,7 +151,7 @@ int ppbo_ctx_create(int device, ppbo_ctx** out) {
   }
   c->qf_variant = env_int("PPBO_QF_VARIANT", 4);
   if (c->qf_variant < 0 || c->qf_variant > 5) c->qf_variant = 0;
-  c->qf_order = env_int("PPBO_QF_ORDER", 514);
+  c->qf_order = env_int("PPBO_QF_ORDER", -1);      // -1: by size (launch_quadform)
   c->line_y_chunk = env_int("PPBO_LINE_Y_CHUNK", 0);
   c->syrk_cfg = env_int("PPBO_SYRK_CFG", 0);
   c->fit_overlap = env_int("PPBO_FIT_OVERLAP", 1);

@@ -44,7 +44,7 @@ struct ppbo_ctx {
   std::vector<const void*> lds_raised;
   std::vector<int> lds_raised_bytes;
   // tuning knobs, read from the environment once per ctx (ppbo_ctx_create); defaults = measured best
-  int qf_variant = 4, qf_order = 514, potrf_gen = 3, rff_nt = 0, gram_variant = -1, rff_score_mfma = 1;
+  int qf_variant = 4, qf_order = -1, potrf_gen = 3, rff_nt = 0, gram_variant = -1, rff_score_mfma = 1;
   // PPBO_FUSED: 1 (default) = models of up to 1024 rows are scored by the one-launch kernel of fused.hip, 0 = always the
   // three-launch form (kstar -> quadform -> score)
   int fused_score = 1;

@@ -329,7 +329,10 @@ int launch_quadform(ppbo_ctx* ctx, const double* G, int N, int g_rows, int n_row
   ppbo_lds_limit(ctx, (const void*)quadform_kernel<C, MINW, false>, (int)lds);
   const int ntm = (g_rows + C::BM - 1) / C::BM, ntn = (Mc + C::BN - 1) / C::BN;
   const int grid = ntm * ntn;
-  const int order = ctx->qf_order;   // PPBO_QF_ORDER; default 514 = candidate-tile fastest in chunks of 128 tiles (measured best: profiles/r04_quadform_traffic_vs_order.txt)
+  // PPBO_QF_ORDER; default: candidate-tile fastest in chunks of 128 tiles (514; measured best at N >= 2048:
+  // profiles/r04_quadform_traffic_vs_order.txt), of 256 tiles up to N = 1024 (1026: the same 268 MB of K* per chunk as 128
+  // tiles at N = 2048; round 6, interleaved on one box at C4: 0.899-0.903 against 0.891-0.894 of the MFMA peak)
+  const int order = ctx->qf_order >= 0 ? ctx->qf_order : (N <= 1024 ? 1026 : 514);
   const int swz = (grid >= 64 ? (order & 1) : 0) | (order & ~1);
   // every tile in bounds, 16-byte aligned, and every K range a multiple of 16?
   const bool fast = (g_rows % C::BM == 0) && (ldk >= ntn * C::BN) && (N % BK == 0) && (ldk % 2 == 0) &&
