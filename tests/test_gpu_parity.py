@@ -26,6 +26,11 @@ def host(t):
 
 
 def rel(a, b):
+    """Relative difference IN THE MAX NORM: max|a - b| / max|b| (not elementwise).  That is the norm every "relative"
+    tolerance of this file is stated in -- north_star's "within 1e-5 relative" included: posterior means change sign
+    across a candidate set and variances go to ~1e-6 sigma_f^2 at the design points, so an elementwise ratio would be
+    dominated by the entries whose reference value is a rounding residue.  Variances are additionally held to an
+    absolute bound in units of sigma_f^2 where they are tested."""
     return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, np.max(np.abs(b)))
 
 
