@@ -32,7 +32,9 @@
 // Up to 256 + rows a workgroup is 8 wavefronts with a 256-row panel (76 KB of LDS): two workgroups share a CU and one's
 // K* phase runs under the other's MFMAs.  Above that, 16 wavefronts and a 512-row panel (149 KB), one workgroup per CU.
 // Larger models, the camphor kernel and the fp32-K* report keep the three-launch form.
+#include <cstdio>
 #include <type_traits>
+#include <vector>
 
 #include "gemm_f64.h"
 #include "score.h"
@@ -55,8 +57,9 @@ struct FusedArgs {
   double sf2; int kind; double mustar; long long idx_base;
   double* mu_out; double* var_out; double* score_out; Best* blk_best;
   int ncu, delay;                        // CUs of the device; start delay of the odd dispatch rounds (x 3.4 us)
+  unsigned long long* stamps;            // dbg bit 3: [blocks][16] s_memrealtime stamps of wavefront 0 at the phase boundaries
   int dbg;      // PPBO_FUSED_DBG (measurement only): bit 0 = no kernel evaluations, bit 1 = no contraction,
-                // bit 2 = the contraction re-uses its first four chunks of G (no loads in its loop)
+                // bit 2 = the contraction re-uses its first four chunks of G (no loads in its loop), bit 3 = phase stamps
 };
 
 // A fragments of one 16-deep chunk of a 16-row strip: f[s] = Gt[k0 + 4 q + s][r0 + r] for lane (r, q)
@@ -275,6 +278,8 @@ __global__ __launch_bounds__(64 * NW, 4) void fused_score_kernel(const FusedArgs
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lr = lane & 15, lk = lane >> 4;
   const int N = a.N, D = a.D, mblk = a.mblk, R1 = a.R1;
+#define FSTAMP(k) do { if (a.stamps && t == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  FSTAMP(0);
   const long long cand0 = (long long)blockIdx.x * FS_BN;
   // Two workgroups of 8 wavefronts share a CU.  Dispatched together they run in lockstep -- both in their K* phases (matrix
   // cores idle), then both contracting -- and nothing overlaps.  The workgroups of every second dispatch round (the ones
@@ -346,6 +351,7 @@ __global__ __launch_bounds__(64 * NW, 4) void fused_score_kernel(const FusedArgs
       s_obs[t] = (t - rb) * LD * 8;
     }
     __syncthreads();                       // parameters staged; and (second pass) everybody is done with the first panel
+    FSTAMP(FIRST ? 1 : 6);
     // ---- K* phase: r^2 = (|x|^2 + |c|^2) - 2 x.c, the reference's expansion (kernels.py:7-10), with the x.c of a
     // 16-row x 16-candidate tile on the matrix cores: the accumulator starts at |x|^2 + |c|^2, the B operand is -2 c.
     // A wavefront forms rows [32 wave, 32 wave + 32) of the panel: two row tiles x two column tiles, 16 dimensions per
@@ -401,6 +407,7 @@ __global__ __launch_bounds__(64 * NW, 4) void fused_score_kernel(const FusedArgs
       }
     }
     __syncthreads();
+    FSTAMP(FIRST ? 2 : 7);
     // ---- the star-edge part of k*' Lambda k* from the finished panel: sum_j (2 lam_off,j) k_j k_obs(j); thread =
     // (candidate, 16 consecutive rows).  2 lam_off (zero on observation rows and behind the pass's rows) and the panel
     // offset of a row's observation row were staged with the parameters: three vector instructions per element
@@ -415,6 +422,7 @@ __global__ __launch_bounds__(64 * NW, 4) void fused_score_kernel(const FusedArgs
         tl = fma(lo2 * kv, ko, tl);
       }
     }
+    FSTAMP(FIRST ? 3 : 8);
     // ---- contraction phase: K range [P0, .) of this pass, panel row 0 = K* row P0 ---------------------------------------
     // strips a = `wave` (short K range) and b = 2 NW - 1 - wave (long) of either kind, as a pair (fs_pair)
     if (!(a.dbg & 2)) {
@@ -462,7 +470,9 @@ __global__ __launch_bounds__(64 * NW, 4) void fused_score_kernel(const FusedArgs
     }
   };
   pass(std::true_type{}, 0, R1);
+  FSTAMP(4);
   if (R1 < N) pass(std::false_type{}, R1, N);
+  FSTAMP(9);
   // ---- finish: per-candidate sums over the wavefronts (fixed order), variance, score, the block's best --------------
   __syncthreads();                         // the panel is free: reuse it
   double* red_q = lds_dyn;                 // [NW][32]
@@ -483,6 +493,7 @@ __global__ __launch_bounds__(64 * NW, 4) void fused_score_kernel(const FusedArgs
   }
   if (lane < 32) red_t[wave * 32 + lane] = tl;
   __syncthreads();
+  FSTAMP(10);
   if (t >= 64) return;
   const long long cand = cand0 + t;
   Best b{0.0, -1};
@@ -516,6 +527,8 @@ __global__ __launch_bounds__(64 * NW, 4) void fused_score_kernel(const FusedArgs
     b = best_merge(b, other);
   }
   if (t == 0) a.blk_best[blockIdx.x] = b;
+  FSTAMP(11);
+#undef FSTAMP
 }
 
 // the pass structure for a model of N rows with stars of mblk rows under a panel of KP rows: R1 = rows of the first pass
@@ -627,12 +640,45 @@ int ppbo_fused_score(ppbo_ctx* ctx, const ppbo_model* m, const double* Gt, int l
   a.Xc = d_Xc; a.M = M; a.Gt = Gt; a.ldgt = ldgt; a.R1 = m->N;
   a.sf2 = m->theta[2] * m->theta[2]; a.kind = score_kind; a.mustar = mustar; a.idx_base = idx_base;
   a.mu_out = d_mu; a.var_out = d_var; a.score_out = d_score; a.blk_best = (Best*)blk_best;
-  a.dbg = ctx->fused_dbg & 15;
+  a.dbg = ctx->fused_dbg & 7;
+  a.stamps = nullptr;
+  const long long nblk_dbg = (M + FS_BN - 1) / FS_BN;
+  if (ctx->fused_dbg & 8) {                // phase stamps (measurement only): wavefront 0 of every workgroup
+    a.stamps = (unsigned long long*)ppbo_workspace(ctx, ppbo_ctx::WS_SEARCH_ROWS, (size_t)nblk_dbg * 16 * sizeof(unsigned long long));
+    if (a.stamps) (void)hipMemsetAsync(a.stamps, 0, (size_t)nblk_dbg * 16 * sizeof(unsigned long long), s);
+  }
   a.ncu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   a.delay = (ctx->fused_dbg >> 4) & 15;
+  int rc;
   switch (m->kernel_id) {
-    case PPBO_KERNEL_SE: return fused_launch<PPBO_KERNEL_SE>(ctx, a, s);
-    case PPBO_KERNEL_RQ: return fused_launch<PPBO_KERNEL_RQ>(ctx, a, s);
+    case PPBO_KERNEL_SE: rc = fused_launch<PPBO_KERNEL_SE>(ctx, a, s); break;
+    case PPBO_KERNEL_RQ: rc = fused_launch<PPBO_KERNEL_RQ>(ctx, a, s); break;
     default: return ppbo_set_error(ctx, -1, "the one-launch scoring kernel takes the SE and RQ kernels");
   }
+  if (rc == 0 && a.stamps) {               // mean phase lengths over the workgroups, in us (s_memrealtime ticks at 100 MHz)
+    std::vector<unsigned long long> h((size_t)nblk_dbg * 16);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), a.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    static const char* names[12] = {"start", "pass1 parameters", "pass1 K* tiles", "pass1 star edges", "pass1 contraction", "",
+                                    "pass2 parameters", "pass2 K* tiles", "pass2 star edges", "pass2 contraction",
+                                    "reductions", "score + best"};
+    double sum[12] = {};
+    unsigned long long t_min = ~0ull, t_max = 0;
+    for (long long b = 0; b < nblk_dbg; ++b) {
+      unsigned long long prev = h[b * 16];
+      if (prev < t_min) t_min = prev;
+      for (int k = 1; k < 12; ++k) {
+        const unsigned long long v = h[b * 16 + k];
+        if (v == 0) continue;
+        sum[k] += (double)(v - prev) * 0.01;
+        prev = v;
+        if (v > t_max) t_max = v;
+      }
+    }
+    fprintf(stderr, "[fused stamps] %lld workgroups, first start to last end %.1f us; mean per workgroup:", nblk_dbg, (double)(t_max - t_min) * 0.01);
+    for (int k = 1; k < 12; ++k)
+      if (names[k][0]) fprintf(stderr, " %s %.2f |", names[k], sum[k] / (double)nblk_dbg);
+    fprintf(stderr, "\n");
+  }
+  return rc;
 }
