@@ -1,7 +1,7 @@
-"""Rewrites the C3-strong table of DESIGN.md section 6 from profiles/r04_scaling_prediction.txt."""
+"""Rewrites the C3-strong table of DESIGN.md section 6 from profiles/r06_scaling_prediction.txt."""
 import os, re
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-txt = open(os.path.join(R, "profiles", "r04_scaling_prediction.txt")).read()
+txt = open(os.path.join(R, "profiles", "r06_scaling_prediction.txt")).read()
 blocks = [b for b in txt.split("\n\n") if b.lstrip().startswith("# C3")]
 rows = {}
 for bi, b in enumerate(blocks[:2]):
