@@ -110,6 +110,9 @@ class Engine:
             # posterior here (the library would otherwise do it in a workspace on every call)
             if post.Gt is None or post.Gt.device != post.G.device:
                 post.Gt = self.transposed_G(post.G)
+                # once per posterior: the transpose is complete before ANY stream (another engine's, a side thread's) can
+                # be handed the pointer through this Posterior
+                torch.cuda.current_stream(self.device).synchronize()
             md.d_Gt = post.Gt.data_ptr()
         return md
 
