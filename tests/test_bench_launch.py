@@ -60,7 +60,14 @@ def test_gpus_1_line_is_well_formed():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["name"] == "c2"
     assert line["config"]["M_total"] == 16384 and line["ms_per_step_with_event_brackets"] > 0
-    assert 0 < line["roofline"]["frac"] <= 1.0 and line["roofline"]["traffic"] is None
+    assert 0 < line["roofline"]["frac"] <= 1.0
+    # `traffic` = the counter figure of the committed PMC capture when it was taken at THIS launch shape (round 6:
+    # profiles/r06_pmc_hot_kernels.json holds the C2 launch of the one-launch scoring kernel), null otherwise; either way
+    # the algorithmic bytes stand beside it and the source says whether the capture belongs to the tree's kernel sources
+    tr, src = line["roofline"]["traffic"], line["roofline"].get("traffic_source")
+    assert line["roofline"]["algorithmic_bytes"] > 0
+    assert tr is None or (tr > 0 and src["shape_matches_this_launch"] and isinstance(src["current"], bool)
+                          and abs(line["roofline"]["traffic_over_algorithmic"] - tr / line["roofline"]["algorithmic_bytes"]) < 1e-9)
     assert line["roofline"]["dense_equivalent_tflops"] >= line["roofline"]["achieved"]
 
 
