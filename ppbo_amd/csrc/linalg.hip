@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int NB = 64;
+typedef unsigned v2u32_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ double lane_bcast(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -230,6 +231,72 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
   }
 }
 
+// ---- one 16-column slab of the diagonal block, ONE wavefront, lane = row (see potrf_panel_part).
+// A lone wavefront issues in order; what a lane broadcast costs it (tools/dev/bcast_bench.hip): two v_readlane and the
+// fma that uses them 23.6 cycles, against 5.8 for an fma on registers -- the 136 broadcasts of a left-looking slab were
+// two thirds of its 2.4 us.  Hence:
+//  * right-looking, and column j-1's multipliers L[c0 + k][j - 1], k > j, are read back from LDS, where the finished
+//    column is stored anyway: one ds_read_b64 with a uniform address (a broadcast, no bank conflict) per multiplier,
+//    all issued at the top of a stage and consumed under the pivot chain;
+//  * only the pivot and the NEXT column's newest multiplier go through v_readlane, both taken from the unscaled column
+//    in one round trip: L[c0 + j + 1][j] = v[lane c0 + j + 1] * rs, scaled by the same product the lane itself forms
+//    (bit-identical to broadcasting a[j] afterwards);
+//  * the pivot of column j (rsqrt + two Newton steps + scale: one dependent chain) is interleaved BY HAND with the
+//    rank-1 update column j-1 applies to the columns right of j; the scheduler fences keep that order (hipcc sinks
+//    every update to its use otherwise, and the two chains run one after the other).
+// Every element still receives its updates in column order: the bits of the left-looking form.
+struct SlabState {
+  double a[16];       // the slab's columns of this lane's row: final (scaled) left of the current column
+  double ap;          // column j-1, scaled
+  double piv[16];     // the pivots (wave-uniform): scanned for the first non-positive one only if the LAST is not positive
+};
+
+template <int K0, int K1>
+__device__ __forceinline__ void slab_fill(SlabState& st, const double (&mk)[16]) {
+#pragma unroll
+  for (int k = K0; k < K1; ++k) st.a[k] -= st.ap * mk[k];
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int J>
+__device__ __forceinline__ void slab_column(SlabState& st, double* __restrict__ Ab, double* __restrict__ Rinv, int c0, int lane) {
+  // the multipliers are on their way from LDS while the first half of the pivot chain runs (a wait for them would
+  // hold the chain too: one wavefront, in order); the updates share the second half, THIRD at a time
+  constexpr int NF = (J > 0) ? 15 - J : 0, PER = (NF + 2) / 3, F = J + 1;     // column j-1 updates columns F .. 15
+  constexpr auto at = [](int q) { return (F + q * PER < 16) ? F + q * PER : 16; };
+  const double v = st.a[J];
+  const double d = lane_bcast(v, c0 + J);
+  const double mraw = (J < 15) ? lane_bcast(v, c0 + J + 1) : 0.0;
+  __builtin_amdgcn_sched_barrier(0);
+  double mk[16];
+#pragma unroll
+  for (int k = F; k < 16; ++k) mk[k] = (J > 0) ? Ab[(c0 + k) * BLD + c0 + J - 1] : 0.0;
+  double y = __builtin_amdgcn_rsq(d);               // v_rsq_f64, ~26 bits; two Newton steps (as rsqrt_refined)
+  const double h = -0.5 * d;
+  st.piv[J] = d;      // a non-positive pivot turns everything right of it into NaN (rsq of d <= 0 is NaN or inf, inf * -0 too)
+  double tq = y * y;
+  double u = fma(h, tq, 1.5);
+  y = y * u;
+  tq = y * y;
+  __builtin_amdgcn_sched_barrier(0);
+  slab_fill<at(0), at(1)>(st, mk);
+  u = fma(h, tq, 1.5);
+  slab_fill<at(1), at(2)>(st, mk);
+  y = y * u;
+  slab_fill<at(2), 16>(st, mk);
+  const double aj = v * y;
+  if (J < 15) st.a[J + 1] -= aj * (mraw * y);
+  st.a[J] = aj;
+  st.ap = aj;
+  // Final; the next stage reads its multipliers here.  Every lane stores, unmasked: rows above the diagonal receive
+  // garbage, which nothing reads (the block's consumers touch its lower triangle only; the copy to diag_out zeroes
+  // the upper one) -- the select and the exec mask were 5 of a column's ~40 instructions.  1 / l_jj: the same value
+  // from every lane to one address.
+  Ab[lane * BLD + c0 + J] = aj;
+  Rinv[c0 + J] = y;
+  if constexpr (J < 15) slab_column<J + 1>(st, Ab, Rinv, c0, lane);
+}
+
 // One launch per panel step, update part: C -= P P^T with P = block column k-1, on the tiles right of block
 // column k.  Persistent: a workgroup walks the folded tile list; the next tile's operands and C values are
 // requested before the current tile's MFMAs, so a tile costs its 64 MFMAs per wavefront, not a memory round
@@ -334,77 +401,86 @@ __device__ __forceinline__ bool potrf_panel_part(double* __restrict__ A, int lda
   double& s_fpiv = Rinv[NB + 1];        // the non-positive pivot that stopped the factorization
   const int kb = (N - k0 < NB) ? (N - k0) : NB;
   // global reads, most urgent first (the counter retires them in order): diagonal block and L[k, k-1]
-  // gate the factorization, the wave's own rows are not needed before slab 0 is under way
-  double a11[16], lp[16], afr[16];
+  // gate the factorization, the wave's own rows are not needed before slab 0 is under way.
+  // Through two buffer descriptors (the diagonal block's rows; this wavefront's 16 panel rows), each ending with its
+  // last valid row, so that rows past the block / past N read as zero without a branch, and with per-lane offsets
+  // fixed for the kernel: a load is one add + one instruction.  (As 64 guarded global loads with 64-bit addresses
+  // the requests alone took ~2 us of a step to ISSUE: 12 instructions and a branch each.)
+  const int cbase = has_prev ? k0 - NB : k0, dcol = k0 - cbase;       // leftmost column read: block column k-1
+  const int rowB = lda * 8;                                            // bytes per row (64 rows x lda x 8 < 4 GB)
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+      A + (size_t)k0 * lda + cbase, 0, ((kb - 1) * lda + (N - cbase)) * 8, 0x00020000);
+  const int row0 = __builtin_amdgcn_readfirstlane((wave == 0) ? N : k0 + NB + (blockIdx.x * 3 + wave - 1) * 16);
+  const int nrow = (N - row0 < 16) ? (N - row0 < 0 ? 0 : N - row0) : 16;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      A + (size_t)(nrow ? row0 : k0) * lda + cbase, 0, nrow ? ((nrow - 1) * lda + (N - cbase)) * 8 : 0, 0x00020000);
+  auto ldb = [](__amdgpu_buffer_rsrc_t r, int off) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+  };
+  // the first step has no block column k-1: the same loads through descriptors of size zero (no request leaves the
+  // CU, the code stays one straight line -- with a branch around them hipcc waited for the first 32 loads before it
+  // issued the rest)
+  const __amdgpu_buffer_rsrc_t rdp = __builtin_amdgcn_make_buffer_rsrc(
+      A + (size_t)k0 * lda + cbase, 0, has_prev ? ((kb - 1) * lda + (N - cbase)) * 8 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(
+      A + (size_t)(nrow ? row0 : k0) * lda + cbase, 0, (nrow && has_prev) ? ((nrow - 1) * lda + (N - cbase)) * 8 : 0, 0x00020000);
+  // 16-byte requests where a lane's elements are neighbours (the block and L[k, k-1]: two columns per lane; the
+  // wave's rows of block column k-1: see the k order below): 40 requests per lane instead of 64 -- a wavefront cannot
+  // have more than 63 in flight, the 64th waited for the first to return
+  auto ldb2 = [](__amdgpu_buffer_rsrc_t r, int off) {
+    return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  };
+  double2_t a11[8], lp[8], afr[8];
+  const int vd = (t >> 5) * rowB + (t & 31) * 16;                      // elements (t >> 5, cbase + 2 (t & 31) + {0, 1}) of the block's rows
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int e = t + 256 * q, r = e >> 6, c = e & 63;
-    a11[q] = (r < kb && c <= r) ? A[(size_t)(k0 + r) * lda + k0 + c] : 0.0;   // zero is the only 'else' that keeps the loads in flight together
-  }
-  if (has_prev) {
+  for (int q = 0; q < 8; ++q) a11[q] = ldb2(rd, vd + 8 * q * rowB + dcol * 8);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int e = t + 256 * q, r = e >> 6, c = e & 63;
-      lp[q] = (r < kb) ? A[(size_t)(k0 + r) * lda + (k0 - NB) + c] : 0.0;
-    }
-  }
-  const int row0 = (wave == 0) ? N : k0 + NB + (blockIdx.x * 3 + wave - 1) * 16;
+  for (int q = 0; q < 8; ++q) lp[q] = ldb2(rdp, vd + 8 * q * rowB);
+  __builtin_amdgcn_sched_barrier(0);      // hipcc's scheduler would put the wave's own rows first
   double4_t rowv[4];
-  if (has_prev) {
+  // A operand of the wave's own update, k order permuted: MFMA step 2 j + h takes column 8 j + 2 lk + h from lane
+  // (lr, lk), on both operands (the B side reads L[k, k-1] from LDS in the same order)
+  const int va = lr * rowB + lk * 16;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
-      afr[kk] = (row0 + lr < N) ? A[(size_t)(row0 + lr) * lda + (k0 - NB) + 4 * kk + lk] : 0.0;
-  }
+  for (int j = 0; j < 8; ++j) afr[j] = ldb2(rwp, va + 64 * j);
+  const int vr = lk * rowB + (dcol + lr) * 8;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int gr = row0 + lk + 4 * r;
-      rowv[c][r] = (gr < N) ? A[(size_t)gr * lda + k0 + 16 * c + lr] : 0.0;
-    }
+    for (int r = 0; r < 4; ++r) rowv[c][r] = ldb(rw, vr + 4 * r * rowB + 128 * c);
   if (info_in != 0) return false;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int e = t + 256 * q;
-    Ab[(e >> 6) * BLD + (e & 63)] = ((e >> 6) >= kb && (e >> 6) == (e & 63)) ? 1.0 : a11[q];   // identity padding of a partial last block
-    if (has_prev) Xs[(e >> 6) * BLD + (e & 63)] = lp[q];
+  for (int q = 0; q < 8; ++q) {
+    const int r = (t >> 5) + 8 * q, c = (t & 31) * 2;
+    // lower triangle; identity padding of a partial last block
+    const double2_t v = {(c <= r) ? ((r >= kb && r == c) ? 1.0 : a11[q][0]) : 0.0,
+                         (c + 1 <= r) ? ((r >= kb && r == c + 1) ? 1.0 : a11[q][1]) : 0.0};
+    *reinterpret_cast<double2_t*>(Ab + r * BLD + c) = v;
+    *reinterpret_cast<double2_t*>(Xs + r * BLD + c) = lp[q];
   }
   if (t == 0) s_fail = 0;
   __syncthreads();
+  // panel k-1's update of the diagonal block, tile (rb, cb) -= L[k, k-1](rb) L[k, k-1](cb)^T with L[k, k-1] staged in Xs.
+  // Two accumulators over the even / odd k steps (a dependent fp64 MFMA issues every ~138 cycles, an independent one
+  // every 64).  Only block column 0 gates slab 0 and is done up front, one tile per wavefront; the other six tiles
+  // are updates like any other and are applied by waves 1-3 while wave 0 factors: column 1 during slab 0 (before
+  // the first trailing update reads it), columns 2 and 3 during slab 1 (Xs is free until the solves of slab 2).
+  // (All ten tiles up front, three per wavefront, were 2.3 us of every step.)
+  auto diag_tile = [&](int rb, int cb) {
+    const int ra = (16 * rb + lr) * BLD + lk, ca = (16 * cb + lr) * BLD + lk, o = (16 * rb + lk) * BLD + 16 * cb + lr;
+    double4_t d0, d1 = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d0[r] = Ab[o + 4 * r * BLD];
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2) {
+      d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra + 4 * kk], Xs[ca + 4 * kk], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra + 4 * kk + 4], Xs[ca + 4 * kk + 4], d1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ab[o + 4 * r * BLD] = d0[r] + d1[r];
+  };
   if (has_prev) {
-    // panel k-1's update of the diagonal block: its ten lower tiles are dealt 3/3/2/2 over the waves; a wave's
-    // tiles advance together through k so that consecutive MFMAs never share an accumulator (a dependent
-    // fp64 MFMA issues every ~138 cycles, an independent one every 64)
-    // tiles in (cb, rb >= cb) order: (0,0) (1,0) (2,0) (3,0) (1,1) (2,1) (3,1) (2,2) (3,2) (3,3); wave w owns
-    // entries w, w+4, w+8 (waves 2 and 3 run a discarded copy of the last tile: no branch in the MFMA loop)
-    const int rb0 = wave, cb0 = 0;
-    const int rb1 = (wave < 3) ? wave + 1 : 2, cb1 = (wave < 3) ? 1 : 2;
-    const int rb2 = 3, cb2 = (wave == 0) ? 2 : 3;
-    const int ra0 = (16 * rb0 + lr) * BLD + lk, ca0 = (16 * cb0 + lr) * BLD + lk;
-    const int ra1 = (16 * rb1 + lr) * BLD + lk, ca1 = (16 * cb1 + lr) * BLD + lk;
-    const int ra2 = (16 * rb2 + lr) * BLD + lk, ca2 = (16 * cb2 + lr) * BLD + lk;
-    const int o0 = (16 * rb0 + lk) * BLD + 16 * cb0 + lr;
-    const int o1 = (16 * rb1 + lk) * BLD + 16 * cb1 + lr;
-    const int o2 = (16 * rb2 + lk) * BLD + 16 * cb2 + lr;
-    double4_t d0, d1, d2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      d0[r] = Ab[o0 + 4 * r * BLD];
-      d1[r] = Ab[o1 + 4 * r * BLD];
-      d2[r] = Ab[o2 + 4 * r * BLD];
-    }
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra0 + 4 * kk], Xs[ca0 + 4 * kk], d0, 0, 0, 0);
-      d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra1 + 4 * kk], Xs[ca1 + 4 * kk], d1, 0, 0, 0);
-      d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[ra2 + 4 * kk], Xs[ca2 + 4 * kk], d2, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      Ab[o0 + 4 * r * BLD] = d0[r];
-      Ab[o1 + 4 * r * BLD] = d1[r];
-      if (wave < 2) Ab[o2 + 4 * r * BLD] = d2[r];
-    }
+    diag_tile(wave, 0);
     __syncthreads();
   }
   double* xs = Xs + wave * 16 * BLD;
@@ -435,8 +511,9 @@ __device__ __forceinline__ bool potrf_panel_part(double* __restrict__ A, int lda
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       xs[(lk + 4 * r) * BLD + 16 * c + lr] = x[r];
-      const int gr = row0 + lk + 4 * r;
-      if (gr < N) A[(size_t)gr * lda + k0 + 16 * c + lr] = x[r];
+      // (two halves by hand: __builtin_bit_cast of an ext-vector ELEMENT stored element 0 four times)
+      const v2u32_t w = {(unsigned)__double2loint(x[r]), (unsigned)__double2hiint(x[r])};
+      __builtin_amdgcn_raw_buffer_store_b64(w, rw, vr + 4 * r * rowB + 128 * c, 0, 0);   // rows >= N: dropped
     }
     __builtin_amdgcn_wave_barrier();
   };
@@ -444,43 +521,37 @@ __device__ __forceinline__ bool potrf_panel_part(double* __restrict__ A, int lda
   for (int s = 0; s < 4; ++s) {
     const int c0 = 16 * s;
     if (wave == 0) {
-      // left-looking within the slab: column j first collects the contributions of columns k < j -- the
-      // multipliers it needs all sit in ONE lane (row c0+j) and are consumed as they are broadcast.  (Written
-      // right-looking, the compiler sinks every update to its use anyway and then spills the 120 live
-      // broadcasts of a slab from SGPRs to VGPR lanes.)  A lone wavefront retires ~1 instruction per 8
-      // cycles here, so the slab costs its instruction count; hence no select for the pivot lane
-      // (its v IS d, so v * rs = sqrt(d)) and one reciprocal-pivot store per slab instead of per column.
-      double a[16];
+      SlabState st;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) a[j] = Ab[lane * BLD + c0 + j];
+      for (int j = 0; j < 16; ++j) st.a[j] = Ab[lane * BLD + c0 + j];
+      st.ap = 0.0;
+      slab_column<0>(st, Ab, Rinv, c0, lane);
       int fail = 0;
-      double rsv = 0.0, fpiv = 0.0;
+      double fpiv = 0.0;
+      if (!(st.piv[15] > 0.0)) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double v = a[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) v -= a[k] * lane_bcast(a[k], c0 + j);
-        const double d = lane_bcast(v, c0 + j);
-        if (!(d > 0.0) && fail == 0) { fail = c0 + j + 1; fpiv = d; }
-        const double rs = rsqrt_refined(d);
-        a[j] = v * rs;
-        rsv = (lane == c0 + j) ? rs : rsv;
-      }
-      if (lane >= c0) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) Ab[lane * BLD + c0 + j] = (c0 + j <= lane) ? a[j] : 0.0;
-        if (lane < c0 + 16) Rinv[lane] = rsv;
+        for (int j = 15; j >= 0; --j)
+          if (!(st.piv[j] > 0.0)) { fail = c0 + j + 1; fpiv = st.piv[j]; }
       }
       if (fail && lane == 0 && s_fail == 0) { s_fail = fail; s_fpiv = fpiv; }
     } else {
+      if (s == 1 && has_prev) {
+        if (wave == 1) { diag_tile(2, 2); diag_tile(3, 2); }
+        if (wave == 2) diag_tile(3, 3);
+      }
       if (s == 0 && has_prev) {
+        diag_tile(wave, 1);
         // panel k-1's update of this wave's rows of block column k (L[k, k-1] is still staged in Xs)
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-          const double av = -afr[kk];
+        for (int j = 0; j < 8; ++j) {
+          double2_t bv[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            rowv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xs[(16 * c + lr) * BLD + 4 * kk + lk], rowv[c], 0, 0, 0);
+          for (int c = 0; c < 4; ++c) bv[c] = *reinterpret_cast<const double2_t*>(Xs + (16 * c + lr) * BLD + 8 * j + 2 * lk);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              rowv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-afr[j][h], bv[c][h], rowv[c], 0, 0, 0);
         }
       }
       if (s >= 1 && wave == 3) invert_diag16(Ab, Rinv, Li + (s - 1) * 16 * 18, 18, s - 1, lane);
@@ -521,7 +592,7 @@ __device__ __forceinline__ bool potrf_panel_part(double* __restrict__ A, int lda
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int e = t + 256 * q;
-      diag_out[e] = Ab[(e >> 6) * BLD + (e & 63)];
+      diag_out[e] = ((e & 63) <= (e >> 6)) ? Ab[(e >> 6) * BLD + (e & 63)] : 0.0;     // the slabs leave garbage above the diagonal
     }
     if (s_fail && t == 0) {
       *info = k0 + s_fail;
