@@ -196,13 +196,28 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
                                               double* __restrict__ out, int ldo, int b, int lane) {
   if (lane >= 16) return;
   const int h = lane >> 3, cc = lane & 7, c0 = 16 * b, o = c0 + 8 * h;
+  // Every LDS read of the first two phases up front: their addresses depend on nothing computed here, and one
+  // wavefront pays a read's ~130 cycles in full whenever it has to wait for one (read row by row, behind the selects'
+  // branches, the inverse took 1.9 us: more than the slab factor it has to hide under).  No select either: for the
+  // rows above the column's own the substitution yields 0 by itself.
+  double l[8][8], ri[8], l21[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    ri[r] = Rinv[o + r];
+#pragma unroll
+    for (int k = 0; k < r; ++k) l[r][k] = Ab[(o + r) * BLD + o + k];
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) l21[r][k] = Ab[(c0 + 8 + r) * BLD + c0 + k];
   double y[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     double v = (r == cc) ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < r; ++k) v -= Ab[(o + r) * BLD + o + k] * y[k];
-    y[r] = (r >= cc) ? v * Rinv[o + r] : 0.0;
+    for (int k = 0; k < r; ++k) v -= l[r][k] * y[k];
+    y[r] = v * ri[r];
   }
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -213,19 +228,24 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (h == 0) {
+    double i22[8][8];                                       // inv(L22), written by lanes 8-15 just now
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int j = 0; j <= r; ++j) i22[r][j] = out[(8 + r) * ldo + 8 + j];
     double tv[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       double v = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v += Ab[(c0 + 8 + r) * BLD + c0 + k] * y[k];
+      for (int k = 0; k < 8; ++k) v += l21[r][k] * y[k];
       tv[r] = v;
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       double v = 0.0;
 #pragma unroll
-      for (int j = 0; j <= r; ++j) v -= out[(8 + r) * ldo + 8 + j] * tv[j];
+      for (int j = 0; j <= r; ++j) v -= i22[r][j] * tv[j];
       out[(8 + r) * ldo + cc] = v;
     }
   }
@@ -234,17 +254,17 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
 // ---- one 16-column slab of the diagonal block, ONE wavefront, lane = row (see potrf_panel_part).
 // A lone wavefront issues in order; what a lane broadcast costs it (tools/dev/bcast_bench.hip): two v_readlane and the
 // fma that uses them 23.6 cycles, against 5.8 for an fma on registers -- the 136 broadcasts of a left-looking slab were
-// two thirds of its 2.4 us.  Hence:
+// two thirds of its time (2.3 us inside the panel kernel, 1.5-1.7 us in this form).  Hence:
 //  * right-looking, and column j-1's multipliers L[c0 + k][j - 1], k > j, are read back from LDS, where the finished
 //    column is stored anyway: one ds_read_b64 with a uniform address (a broadcast, no bank conflict) per multiplier,
 //    all issued at the top of a stage and consumed under the pivot chain;
 //  * only the pivot and the NEXT column's newest multiplier go through v_readlane, both taken from the unscaled column
 //    in one round trip: L[c0 + j + 1][j] = v[lane c0 + j + 1] * rs, scaled by the same product the lane itself forms
 //    (bit-identical to broadcasting a[j] afterwards);
-//  * the pivot of column j (rsqrt + two Newton steps + scale: one dependent chain) is interleaved BY HAND with the
+//  * the pivot of column j (rsqrt + one third-order step + scale: one dependent chain) is interleaved BY HAND with the
 //    rank-1 update column j-1 applies to the columns right of j; the scheduler fences keep that order (hipcc sinks
 //    every update to its use otherwise, and the two chains run one after the other).
-// Every element still receives its updates in column order: the bits of the left-looking form.
+// Every element still receives its updates in column order, as in the left-looking form.
 struct SlabState {
   double a[16];       // the slab's columns of this lane's row: final (scaled) left of the current column
   double ap;          // column j-1, scaled
@@ -271,18 +291,19 @@ __device__ __forceinline__ void slab_column(SlabState& st, double* __restrict__ 
   double mk[16];
 #pragma unroll
   for (int k = F; k < 16; ++k) mk[k] = (J > 0) ? Ab[(c0 + k) * BLD + c0 + J - 1] : 0.0;
-  double y = __builtin_amdgcn_rsq(d);               // v_rsq_f64, ~26 bits; two Newton steps (as rsqrt_refined)
-  const double h = -0.5 * d;
-  st.piv[J] = d;      // a non-positive pivot turns everything right of it into NaN (rsq of d <= 0 is NaN or inf, inf * -0 too)
-  double tq = y * y;
-  double u = fma(h, tq, 1.5);
-  y = y * u;
-  tq = y * y;
+  // 1 / sqrt(d): v_rsq_f64 (~26 bits) and ONE third-order step, y0 (1 + e (1/2 + 3/8 e)) with e = 1 - d y0^2 -- the
+  // remaining error is (5/16) e^3, far below an ulp -- five dependent-chain instructions instead of the seven of two
+  // Newton steps (rsqrt_refined).  A non-positive pivot turns everything right of it into NaN (rsq of d < 0 is NaN,
+  // of 0 inf and 0 * inf NaN): the pivots are scanned for the first one only if the last is not positive.
+  const double y0 = __builtin_amdgcn_rsq(d);
+  st.piv[J] = d;
+  const double dy = d * y0;
+  const double e = fma(-dy, y0, 1.0);
   __builtin_amdgcn_sched_barrier(0);
   slab_fill<at(0), at(1)>(st, mk);
-  u = fma(h, tq, 1.5);
+  const double pq = fma(0.375, e, 0.5), ye = y0 * e;
   slab_fill<at(1), at(2)>(st, mk);
-  y = y * u;
+  const double y = fma(ye, pq, y0);
   slab_fill<at(2), 16>(st, mk);
   const double aj = v * y;
   if (J < 15) st.a[J + 1] -= aj * (mraw * y);
@@ -486,27 +507,26 @@ __device__ __forceinline__ bool potrf_panel_part(double* __restrict__ A, int lda
   double* xs = Xs + wave * 16 * BLD;
   // column block c of this wave's rows: X_c = (R_c - sum_{p<c} X_p L_cp^T) inv(L_cc)^T
   auto solve_block = [&](int c) {
-    double4_t acc = rowv[c];
+    double4_t acc = rowv[c], acc1 = double4_t{0.0, 0.0, 0.0, 0.0};      // two chains: a dependent fp64 MFMA waits ~138 cycles
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       if (p >= c) continue;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const double av = -xs[lr * BLD + 16 * p + kk * 4 + lk];
-        const double bv = Ab[(16 * c + lr) * BLD + 16 * p + kk * 4 + lk];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      for (int kk = 0; kk < 4; kk += 2) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xs[lr * BLD + 16 * p + kk * 4 + lk], Ab[(16 * c + lr) * BLD + 16 * p + kk * 4 + lk], acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xs[lr * BLD + 16 * p + kk * 4 + 4 + lk], Ab[(16 * c + lr) * BLD + 16 * p + kk * 4 + 4 + lk], acc1, 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xs[(lk + 4 * r) * BLD + 16 * c + lr] = acc[r];
+    for (int r = 0; r < 4; ++r) xs[(lk + 4 * r) * BLD + 16 * c + lr] = acc[r] + acc1[r];
     __builtin_amdgcn_wave_barrier();
-    double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+    double4_t x = double4_t{0.0, 0.0, 0.0, 0.0}, x1 = x;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const double av = xs[lr * BLD + 16 * c + kk * 4 + lk];
-      const double bv = Li[(c * 16 + lr) * 18 + kk * 4 + lk];
-      x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+    for (int kk = 0; kk < 4; kk += 2) {
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[lr * BLD + 16 * c + kk * 4 + lk], Li[(c * 16 + lr) * 18 + kk * 4 + lk], x, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[lr * BLD + 16 * c + kk * 4 + 4 + lk], Li[(c * 16 + lr) * 18 + kk * 4 + 4 + lk], x1, 0, 0, 0);
     }
+    x += x1;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
