@@ -200,7 +200,9 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
   // wavefront pays a read's ~130 cycles in full whenever it has to wait for one (read row by row, behind the selects'
   // branches, the inverse took 1.9 us: more than the slab factor it has to hide under).  No select either: for the
   // rows above the column's own the substitution yields 0 by itself.
-  double l[8][8], ri[8], l21[8][8];
+  // (L21 and inv(L22) in halves of four rows: with all of them in registers at once the kernel needed 324 VGPRs, and
+  // two workgroups no longer fitted one CU -- the mode the large-N steps run in: potrf(4096) +3.6 %)
+  double l[8][8], ri[8], la[4][8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     ri[r] = Rinv[o + r];
@@ -208,9 +210,9 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
     for (int k = 0; k < r; ++k) l[r][k] = Ab[(o + r) * BLD + o + k];
   }
 #pragma unroll
-  for (int r = 0; r < 8; ++r)
+  for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) l21[r][k] = Ab[(c0 + 8 + r) * BLD + c0 + k];
+    for (int k = 0; k < 8; ++k) la[r][k] = Ab[(c0 + 8 + r) * BLD + c0 + k];
   double y[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -219,6 +221,21 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
     for (int k = 0; k < r; ++k) v -= l[r][k] * y[k];
     y[r] = v * ri[r];
   }
+  // rows 0-3 of L21 inv(L11) need nothing from the other lanes: formed here, so that the first half of L21 is dead
+  // before the second is requested
+  double tv[8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += la[r][k] * y[k];
+    tv[r] = v;
+  }
+  double lb[4][8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lb[r][k] = Ab[(c0 + 12 + r) * BLD + c0 + k];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     out[(8 * h + r) * ldo + 8 * h + cc] = y[r];
@@ -228,25 +245,27 @@ __device__ __forceinline__ void invert_diag16(const double* __restrict__ Ab, con
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (h == 0) {
-    double i22[8][8];                                       // inv(L22), written by lanes 8-15 just now
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-      for (int j = 0; j <= r; ++j) i22[r][j] = out[(8 + r) * ldo + 8 + j];
-    double tv[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < 4; ++r) {
       double v = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v += l21[r][k] * y[k];
-      tv[r] = v;
+      for (int k = 0; k < 8; ++k) v += lb[r][k] * y[k];
+      tv[4 + r] = v;
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      double v = 0.0;
+    for (int half = 0; half < 2; ++half) {
+      double i22[4][8];                                     // inv(L22), written by lanes 8-15 just now
 #pragma unroll
-      for (int j = 0; j <= r; ++j) v -= i22[r][j] * tv[j];
-      out[(8 + r) * ldo + cc] = v;
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j <= 4 * half + r; ++j) i22[r][j] = out[(8 + 4 * half + r) * ldo + 8 + j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j <= 4 * half + r; ++j) v -= i22[r][j] * tv[j];
+        out[(8 + 4 * half + r) * ldo + cc] = v;
+      }
     }
   }
 }
@@ -644,7 +663,12 @@ __device__ __forceinline__ bool potrf_panel_part(double* __restrict__ A, int lda
 constexpr int STEP_LDS = 82 * 1024;
 constexpr int STEP_LDS_SHARED = (NB * BLD + 4 * 16 * 18 + 4 * 16 * BLD + NB + 2) * (int)sizeof(double);   // what the panel part needs: two per CU
 
-__global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ A, int lda, int N, int k0, int has_prev,
+// Two builds of the same code.  CROWDED = the steps whose trailing update is so large that two workgroups share a CU
+// (see ppbo_potrf_async): two wavefronts per SIMD means at most 256 VGPRs -- hipcc spills 67 of the panel part's
+// values to fit, which costs the lone-workgroup steps 11 % (potrf(2048) 0.53 -> 0.59 ms) but buys the crowded ones
+// their second workgroup (potrf(4096) 1.65 -> 1.53 ms); the other build takes the registers it wants (324).
+template <bool CROWDED>
+__global__ __launch_bounds__(256, CROWDED ? 2 : 1) void potrf_step_kernel(double* __restrict__ A, int lda, int N, int k0, int has_prev,
                                                          int nP, int ntS, double* __restrict__ diag_out,
                                                          int* __restrict__ info, double* __restrict__ fail_pivot) {
   extern __shared__ __attribute__((aligned(16))) double plds[];
@@ -1103,7 +1127,8 @@ int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hi
   PpboProfScope pf(ctx, ppbo_ctx::PF_POTRF, s);
   if (ctx->potrf_gen < 3) set_int_kernel<<<1, 1, 0, s>>>(d_info, 0, d_fail_pivot);   // generation 3: the first step does it
   if (ctx->potrf_gen >= 3) {
-    ppbo_lds_limit(ctx, (const void*)potrf_step_kernel, STEP_LDS);
+    ppbo_lds_limit(ctx, (const void*)potrf_step_kernel<false>, STEP_LDS);
+    ppbo_lds_limit(ctx, (const void*)potrf_step_kernel<true>, STEP_LDS);
     const int npanel = (N + NB - 1) / NB;
     double* diag = (double*)ppbo_workspace(ctx, ppbo_ctx::WS_POTRF, (size_t)npanel * NB * NB * sizeof(double));
     if (!diag) return (int)hipErrorOutOfMemory;
@@ -1119,8 +1144,12 @@ int ppbo_potrf_async(ppbo_ctx* ctx, double* d_A, int N, int lda, int* d_info, hi
       const bool crowded = nS > 900;
       const int slots = (crowded ? 512 : 256) - nP;
       const int nSW = nS < slots ? nS : slots;
-      potrf_step_kernel<<<nP + nSW, 256, crowded ? STEP_LDS_SHARED : STEP_LDS, s>>>(d_A, lda, N, k0, k0 > 0 ? 1 : 0, nP, ntS,
-                                                        diag + (size_t)(k0 / NB) * NB * NB, d_info, d_fail_pivot);
+      if (crowded)
+        potrf_step_kernel<true><<<nP + nSW, 256, STEP_LDS_SHARED, s>>>(d_A, lda, N, k0, k0 > 0 ? 1 : 0, nP, ntS,
+                                                                       diag + (size_t)(k0 / NB) * NB * NB, d_info, d_fail_pivot);
+      else
+        potrf_step_kernel<false><<<nP + nSW, 256, STEP_LDS, s>>>(d_A, lda, N, k0, k0 > 0 ? 1 : 0, nP, ntS,
+                                                                 diag + (size_t)(k0 / NB) * NB * NB, d_info, d_fail_pivot);
     }
     scatter_diag_kernel<<<npanel, 256, 0, s>>>(d_A, lda, N, diag, d_info);
     PPBO_LAUNCH_CHECK(ctx);
