@@ -96,6 +96,36 @@ def test_potrf_reports_not_pd(eng, bad):
     assert ei.value.info == bad + 1
 
 
+@pytest.mark.parametrize("kind", ["negative", "zero", "nan"])
+def test_potrf_failure_column_is_lapacks(eng, kind):
+    """Round 6: the slab factor no longer tests every pivot -- a pivot that is not positive poisons everything right of it
+    with NaN, the LAST pivot of a 16-column slab tells, and only then the slab's pivots are scanned.  Every position class
+    of a slab (first / inner / last column, first / later slab of a 64-column block, first / later block), a negative, an
+    exactly zero and a NaN pivot: `info` is LAPACK's (netlib's, where the NaN is concerned)."""
+    from scipy.linalg import lapack
+    from ppbo_amd.engine import NotPositiveDefinite
+    N = 150
+    rng = np.random.default_rng(5)
+    for bad in (0, 1, 15, 16, 17, 31, 32, 47, 48, 62, 63, 64, 65, 79, 80, 127, 128, 143, 149):
+        if kind == "zero":
+            A = np.diag(1.0 + rng.random(N))            # diagonal: the pivot is the entry itself, exactly
+            A[bad, bad] = 0.0
+        else:
+            Q = rng.standard_normal((N, N))
+            A = Q @ Q.T + N * np.eye(N)
+            A[bad, bad] = -3.0 if kind == "negative" else np.nan
+        info_ref = bad + 1          # netlib dpotrf2: ajj <= 0 or isnan(ajj); the OpenBLAS under SciPy lets a NaN pivot pass
+        if kind != "nan":
+            assert lapack.dpotrf(np.tril(A), lower=1)[1] == info_ref
+        with pytest.raises(NotPositiveDefinite) as ei:
+            eng.potrf_(eng.dev(A))
+        assert ei.value.info == info_ref, (kind, bad)
+    # and the context factors a good matrix right after
+    Q = rng.standard_normal((N, N))
+    A = Q @ Q.T + N * np.eye(N)
+    assert rel(np.tril(host(eng.potrf_(eng.dev(A.copy())))), np.linalg.cholesky(A)) < 1e-12
+
+
 @pytest.mark.parametrize("N,pad", [(200, 8), (257, 3)])
 def test_potrf_with_leading_dimension(eng, N, pad):
     """lda > N (and odd): the factor lands in the view, the padding columns are untouched."""
