@@ -357,8 +357,12 @@ struct WhState {
 };
 
 // rowsq[i] = sum_{k <= i} L[i][k]^2 (= Sigma_ii); their sum is |L|_F^2 >= lambda_max(Sigma)
+// (also zeroes `nzero` doubles at `zero`: the search's state and basis -- as a memset of its own that was a 7-us blit
+// kernel and an 11-us gap in front of it, in every fit)
 __global__ __launch_bounds__(256) void row_sqnorm_kernel(const double* __restrict__ L, int N, int ldl,
-                                                         double* __restrict__ rowsq) {
+                                                         double* __restrict__ rowsq, double* __restrict__ zero,
+                                                         size_t nzero) {
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < nzero; k += (size_t)gridDim.x * 256) zero[k] = 0.0;
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= N) return;
@@ -432,10 +436,14 @@ static_assert(sizeof(WhHead) == offsetof(WhState, B), "WhHead mirrors the head o
 
 __global__ __launch_bounds__(LB_T) void lbfgs_init_kernel(WhState* __restrict__ st, const double* __restrict__ rowsq,
                                                           int N, double gtol, int max_evals, int gf_avail, int gf_from,
-                                                          const int* __restrict__ factor_info, WhProgress prog) {
+                                                          const int* __restrict__ factor_info, WhProgress prog,
+                                                          const double* __restrict__ z0, double* __restrict__ zt) {
   __shared__ double sh[LB_T / 64];
   double s = 0.0;
-  for (int i = threadIdx.x; i < N; i += LB_T) s += rowsq[i];
+  for (int i = threadIdx.x; i < N; i += LB_T) {
+    s += rowsq[i];
+    if (z0) zt[i] = z0[i];              // a start handed over in the whitened variable: the first trial point (was a copy of its own)
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -1289,18 +1297,18 @@ int whitened_search(ppbo_ctx* ctx, const double* d_L, int ldl, const double* d_S
   volatile unsigned long long* h_word = reinterpret_cast<volatile unsigned long long*>(const_cast<double*>(hr.h_rec) + 24);
   const WhHead* h_head = reinterpret_cast<const WhHead*>(const_cast<double*>(hr.h_rec) + 4);
   *h_word = 0;                          // nothing of this ctx is in flight that could write it (one search per ctx at a time)
-  PPBO_HIP_CHECK(ctx, hipMemsetAsync(base, 0, (st_doubles + (size_t)LB_NB * N) * sizeof(double), s));
-  row_sqnorm_kernel<<<(N + 3) / 4, 256, 0, s>>>(d_L, N, ldl, rowsq);
-  lbfgs_init_kernel<<<1, LB_T, 0, s>>>(st, rowsq, N, gtol, max_evals, 1, ex.gf_from, ex.d_factor_info, prog);
+  row_sqnorm_kernel<<<(N + 3) / 4, 256, 0, s>>>(d_L, N, ldl, rowsq, base, st_doubles + (size_t)LB_NB * N);
+  lbfgs_init_kernel<<<1, LB_T, 0, s>>>(st, rowsq, N, gtol, max_evals, 1, ex.gf_from, ex.d_factor_info, prog,
+                                       ex.start_is_z ? d_f_init : nullptr, zt);
   PPBO_LAUNCH_CHECK(ctx);
-  if (ex.start_is_z) {
-    PPBO_HIP_CHECK(ctx, hipMemcpyAsync(zt, d_f_init, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));
-  } else if (ex.d_Linv) {
-    if (int rc = ppbo_gemv_async(ctx, ex.d_Linv, N, N, d_f_init, zt, 0, 1, s)) return rc;     // z0 = L^-1 f_init
-  } else {
-    // z0 = L^-1 f_init = L^T (Sigma^-1 f_init)
-    if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, d_f_init, v, 0, 0, s)) return rc;
-    if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, v, zt, 1, 1, s)) return rc;
+  if (!ex.start_is_z) {
+    if (ex.d_Linv) {
+      if (int rc = ppbo_gemv_async(ctx, ex.d_Linv, N, N, d_f_init, zt, 0, 1, s)) return rc;     // z0 = L^-1 f_init
+    } else {
+      // z0 = L^-1 f_init = L^T (Sigma^-1 f_init)
+      if (int rc = ppbo_gemv_async(ctx, d_Sigma_inv, N, N, d_f_init, v, 0, 0, s)) return rc;
+      if (int rc = ppbo_gemv_async(ctx, d_L, N, ldl, v, zt, 1, 1, s)) return rc;
+    }
   }
   PpboGate run; run.skip_if_nonzero = &st->status;
   PpboGate run_gf = run; run_gf.skip_if_zero = &st->need_gf;
